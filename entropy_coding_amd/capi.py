@@ -1,0 +1,152 @@
+"""ctypes binding of include/cabac_hip.h — test/bench plumbing; the product is the shared library."""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import build_library
+
+NUM_CTX = 379
+REC_BIN = 0x8000
+REC_ALIGN, REC_EP, REC_TRM = 0x1FD, 0x1FE, 0x1FF
+SUB_FINISH, SUB_ALIGN_RBSP = 0x100, 0x200
+CABAC_INIT_B, CABAC_INIT_P, CABAC_INIT_I = 0, 1, 2
+RES_OVERFLOW, RES_BAD_RECORD, RES_UNDERRUN, RES_BAD_STOP = 1, 2, 4, 8
+
+DESC_DTYPE = np.dtype([("rec_offset", "<u8"), ("byte_offset", "<u8"), ("n_records", "<u4"),
+                       ("byte_capacity", "<u4"), ("qp", "<i4"), ("init_id", "<u4")])
+RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
+assert DESC_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 8
+
+EXPORTS = [
+    "cabac_hip_encode_bound", "cabac_hip_init", "cabac_hip_destroy", "cabac_hip_strerror",
+    "cabac_hip_last_error", "cabac_hip_set_stream", "cabac_hip_synchronize", "cabac_hip_set_variant",
+    "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
+    "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
+    "cabac_hip_last_kernel_ms", "cabac_synth_records",
+]
+
+_lib = None
+vp = ctypes.c_void_p
+
+
+def load_library():
+    """Load libcabac_hip.so (building it first if the sources are newer). Loading does not need a GPU;
+    cabac_hip_init does."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = ctypes.CDLL(build_library())
+    L.cabac_hip_encode_bound.restype = ctypes.c_size_t
+    L.cabac_hip_encode_bound.argtypes = [ctypes.c_uint64] * 3
+    L.cabac_hip_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.cabac_hip_destroy.argtypes = [vp]
+    L.cabac_hip_destroy.restype = None
+    L.cabac_hip_strerror.restype = ctypes.c_char_p
+    L.cabac_hip_strerror.argtypes = [ctypes.c_int]
+    L.cabac_hip_last_error.restype = ctypes.c_char_p
+    L.cabac_hip_last_error.argtypes = [vp]
+    L.cabac_hip_set_stream.argtypes = [vp, vp]
+    L.cabac_hip_synchronize.argtypes = [vp]
+    L.cabac_hip_set_variant.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.cabac_hip_encode_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
+    L.cabac_hip_decode_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    L.cabac_hip_ctx_init_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
+    L.cabac_hip_binarize_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
+    L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
+    L.cabac_hip_last_kernel_ms.argtypes = [vp]
+    L.cabac_synth_records.restype = None
+    L.cabac_synth_records.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, vp]
+    _lib = L
+    return L
+
+
+class CabacHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("cabac_hip status %d (%s): %s" % (status, load_library().cabac_hip_strerror(status).decode(), msg))
+        self.status = status
+
+
+def synth_records(seed, substream_index, n_bins, ctx_permille):
+    L = load_library()
+    out = np.empty(n_bins, np.uint16)
+    L.cabac_synth_records(seed, substream_index, n_bins, ctx_permille, out.ctypes.data)
+    return out
+
+
+def encode_bound(n_ctx, n_ep, n_trm):
+    return load_library().cabac_hip_encode_bound(n_ctx, n_ep, n_trm)
+
+
+class CabacHip:
+    """One codec context = one device + one HIP stream.  Raises if there is no GPU (no CPU fallback)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        h = vp()
+        rc = self.L.cabac_hip_init(device, ctypes.byref(h))
+        if rc != 0:
+            raise CabacHipError(rc, "cabac_hip_init(device=%d)" % device)
+        self.h = h
+        if stream is not None:
+            self._check(self.L.cabac_hip_set_stream(self.h, vp(stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cabac_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow_substream=False):
+        if rc != 0 and not (allow_substream and rc == -5):
+            raise CabacHipError(rc, self.L.cabac_hip_last_error(self.h).decode())
+        return rc
+
+    def set_variant(self, enc=0, dec=0):
+        self._check(self.L.cabac_hip_set_variant(self.h, enc, dec))
+
+    def synchronize(self):
+        self._check(self.L.cabac_hip_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        return float(self.L.cabac_hip_last_kernel_ms(self.h))
+
+    # ---- host-pointer entry points (numpy) --------------------------------------------------
+    def encode_batch(self, desc, records, bytes_total, check=True):
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        records = np.ascontiguousarray(records, np.uint16)
+        out = np.zeros(max(int(bytes_total), 1), np.uint8)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        rc = self.L.cabac_hip_encode_batch(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
+                                           out.ctypes.data, int(bytes_total), res.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return out, res
+
+    def decode_batch(self, desc, records, data, check=True):
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        records = np.ascontiguousarray(records, np.uint16)
+        data = np.ascontiguousarray(data, np.uint8)
+        bins = np.zeros(max(len(records), 1), np.uint8)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        rc = self.L.cabac_hip_decode_batch(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
+                                           data.ctypes.data, len(data), bins.ctypes.data, res.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return bins[: len(records)], res
+
+    # ---- device-pointer entry points (raw addresses, e.g. torch tensor .data_ptr()) ----------
+    def encode_device(self, n_sub, d_desc, d_records, d_bytes, d_results):
+        self._check(self.L.cabac_hip_encode_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_bytes), vp(d_results)))
+
+    def decode_device(self, n_sub, d_desc, d_records, d_bytes, d_bins, d_results):
+        self._check(self.L.cabac_hip_decode_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_bytes), vp(d_bins),
+                                                   vp(d_results)))
+
+    def ctx_init_device(self, n_sub, d_qp, d_init_id, d_state, d_rate):
+        self._check(self.L.cabac_hip_ctx_init_device(self.h, n_sub, vp(d_qp), vp(d_init_id), vp(d_state), vp(d_rate)))

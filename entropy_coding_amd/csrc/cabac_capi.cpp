@@ -1,0 +1,296 @@
+// C ABI of libcabac_hip.so (declared in include/cabac_hip.h).  Host-side plumbing only: argument
+// checks, stream/event handling, pinned staging for the host-pointer entry points.  There is no
+// CPU codec in this library — without a GPU cabac_hip_init fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "cabac_hip.h"
+#include "cabac_kernels.h"
+
+struct cabac_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool timed = false;
+  int enc_variant = 0, dec_variant = 0;
+  std::string last_error;
+  // staging for the host-pointer entry points (grown on demand)
+  void *d_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[5] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail_hip(cabac_hip_ctx *c, hipError_t e, const char *what) {
+  if (c) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    c->last_error = buf;
+  }
+  return CABAC_HIP_ERR_HIP;
+}
+
+int fail(cabac_hip_ctx *c, int status, const char *what) {
+  if (c) c->last_error = what;
+  return status;
+}
+
+#define HIP_TRY(c, expr)                                   \
+  do {                                                     \
+    hipError_t _e = (expr);                                \
+    if (_e != hipSuccess) return fail_hip((c), _e, #expr); \
+  } while (0)
+
+int ensure(cabac_hip_ctx *c, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (c->d_cap[slot] >= bytes) return CABAC_HIP_OK;
+  if (c->d_buf[slot]) {
+    HIP_TRY(c, hipFree(c->d_buf[slot]));
+    c->d_buf[slot] = nullptr;
+    c->d_cap[slot] = 0;
+  }
+  size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipMalloc(&c->d_buf[slot], want);
+  if (e != hipSuccess) {
+    c->last_error = "hipMalloc failed";
+    return CABAC_HIP_ERR_NOMEM;
+  }
+  c->d_cap[slot] = want;
+  return CABAC_HIP_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int check_desc_host(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, uint64_t n_records_total,
+                    uint64_t bytes_total) {
+  for (uint32_t s = 0; s < n_sub; s++) {
+    const cabac_substream_desc &d = desc[s];
+    if (d.rec_offset + d.n_records > n_records_total) return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if (d.byte_offset + d.byte_capacity > bytes_total) return fail(c, CABAC_HIP_ERR_INVALID, "bytes out of range");
+    if (d.byte_offset & 15u) return fail(c, CABAC_HIP_ERR_INVALID, "byte_offset must be 16-byte aligned");
+    if ((d.init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
+  }
+  return CABAC_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cabac_hip_encode_bound(uint64_t n_ctx_bins, uint64_t n_ep_bins, uint64_t n_trm_bins) {
+  // <= 6 bits per context bin (contexts.cpp:787-789), 1 per bypass bin, <= 7 per terminate bin,
+  // finish() <= 2 buffered + 2 flushed bytes, alignment <= 1; rounded up to 16.
+  uint64_t bits = 6 * n_ctx_bins + n_ep_bins + 7 * n_trm_bins;
+  uint64_t bytes = (bits + 7) / 8 + 8;
+  return (size_t)((bytes + 15) / 16 * 16);
+}
+
+int cabac_hip_init(int device, cabac_hip_ctx **out) {
+  if (!out) return CABAC_HIP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CABAC_HIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return CABAC_HIP_ERR_INVALID;
+  cabac_hip_ctx *c = new (std::nothrow) cabac_hip_ctx;
+  if (!c) return CABAC_HIP_ERR_NOMEM;
+  c->device = device;
+  DeviceGuard g(device);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    delete c;
+    return CABAC_HIP_ERR_HIP;
+  }
+  c->own_stream = true;
+  *out = c;
+  return CABAC_HIP_OK;
+}
+
+void cabac_hip_destroy(cabac_hip_ctx *c) {
+  if (!c) return;
+  DeviceGuard g(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 5; i++)
+    if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *cabac_hip_strerror(int status) {
+  switch (status) {
+  case CABAC_HIP_OK: return "ok";
+  case CABAC_HIP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+  case CABAC_HIP_ERR_INVALID: return "invalid argument";
+  case CABAC_HIP_ERR_HIP: return "HIP runtime error";
+  case CABAC_HIP_ERR_NOMEM: return "out of memory";
+  case CABAC_HIP_ERR_SUBSTREAM: return "a substream reported an error flag";
+  default: return "unknown status";
+  }
+}
+
+const char *cabac_hip_last_error(const cabac_hip_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+int cabac_hip_set_stream(cabac_hip_ctx *c, void *hip_stream) {
+  if (!c) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  if (c->own_stream && c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+    c->own_stream = false;
+    c->stream = nullptr;
+  }
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_synchronize(cabac_hip_ctx *c) {
+  if (!c) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_set_variant(cabac_hip_ctx *c, int enc, int dec) {
+  if (!c) return CABAC_HIP_ERR_INVALID;
+  c->enc_variant = enc;
+  c->dec_variant = dec;
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_encode_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                            const uint16_t *d_records, uint8_t *d_bytes, cabac_substream_result *d_results) {
+  if (!c || (n_sub && (!d_desc || !d_records || !d_bytes || !d_results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+  HIP_TRY(c, cabac::launch_encode(c->stream, c->enc_variant, n_sub, d_desc, d_records, d_bytes, d_results));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->timed = true;
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_decode_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                            const uint16_t *d_records, const uint8_t *d_bytes, uint8_t *d_bins,
+                            cabac_substream_result *d_results) {
+  if (!c || (n_sub && (!d_desc || !d_records || !d_bytes || !d_bins || !d_results)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+  HIP_TRY(c, cabac::launch_decode(c->stream, c->dec_variant, n_sub, d_desc, d_records, d_bytes, d_bins, d_results));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->timed = true;
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_ctx_init_device(cabac_hip_ctx *c, uint32_t n_sub, const int32_t *d_qp, const uint32_t *d_init_id,
+                              uint32_t *d_state, uint8_t *d_rate) {
+  if (!c || (n_sub && (!d_qp || !d_init_id || !d_state || !d_rate))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, cabac::launch_ctx_init(c->stream, n_sub, d_qp, d_init_id, d_state, d_rate));
+  return CABAC_HIP_OK;
+}
+
+float cabac_hip_last_kernel_ms(cabac_hip_ctx *c) {
+  if (!c || !c->timed) return -1.0f;
+  DeviceGuard g(c->device);
+  if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t n_records_total, uint8_t *bytes, uint64_t bytes_total,
+                           cabac_substream_result *results) {
+  if (!c || (n_sub && (!desc || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (n_sub == 0) return CABAC_HIP_OK;
+  int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
+  if (rc) return rc;
+  DeviceGuard g(c->device);
+  if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
+  if ((rc = ensure(c, 2, bytes_total))) return rc;
+  if ((rc = ensure(c, 3, n_sub * sizeof(cabac_substream_result)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
+  if (n_records_total)
+    HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], records, n_records_total * 2, hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_encode_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint16_t *)c->d_buf[1],
+                               (uint8_t *)c->d_buf[2], (cabac_substream_result *)c->d_buf[3]);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[3], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // copy back only what was produced, substream by substream (payload is ~0.1 B/bin)
+  int status = CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    size_t nbytes = (results[s].n_bits + 7) / 8;
+    if (nbytes > desc[s].byte_capacity) nbytes = desc[s].byte_capacity;
+    if (nbytes)
+      HIP_TRY(c, hipMemcpyAsync(bytes + desc[s].byte_offset, (uint8_t *)c->d_buf[2] + desc[s].byte_offset, nbytes,
+                                hipMemcpyDeviceToHost, c->stream));
+    if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (status) c->last_error = "substream flag set (see results[].flags)";
+  return status;
+}
+
+int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
+                           cabac_substream_result *results) {
+  if (!c || (n_sub && (!desc || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (n_sub == 0) return CABAC_HIP_OK;
+  int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
+  if (rc) return rc;
+  DeviceGuard g(c->device);
+  if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
+  if ((rc = ensure(c, 2, bytes_total))) return rc;
+  if ((rc = ensure(c, 3, n_sub * sizeof(cabac_substream_result)))) return rc;
+  if ((rc = ensure(c, 4, n_records_total))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
+  if (n_records_total)
+    HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], records, n_records_total * 2, hipMemcpyHostToDevice, c->stream));
+  if (bytes_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[2], bytes, bytes_total, hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_decode_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint16_t *)c->d_buf[1],
+                               (const uint8_t *)c->d_buf[2], (uint8_t *)c->d_buf[4],
+                               (cabac_substream_result *)c->d_buf[3]);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[3], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost,
+                            c->stream));
+  if (n_records_total)
+    HIP_TRY(c, hipMemcpyAsync(bins, c->d_buf[4], n_records_total, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t s = 0; s < n_sub; s++)
+    if (results[s].flags) {
+      c->last_error = "substream flag set (see results[].flags)";
+      return CABAC_HIP_ERR_SUBSTREAM;
+    }
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t, const uint64_t *, const uint32_t *, const uint64_t *,
+                              uint32_t *, uint16_t *) {
+  return fail(c, CABAC_HIP_ERR_INVALID, "binarize: not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+// Internal launch interface between the kernels (cabac_kernels.hip) and the C ABI (cabac_capi.cpp).
+#ifndef CABAC_KERNELS_H
+#define CABAC_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cabac_hip.h"
+
+namespace cabac {
+
+hipError_t launch_ctx_init(hipStream_t st, uint32_t n_sub, const int32_t *qp, const uint32_t *init_id, uint32_t *state,
+                           uint8_t *rate);
+hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
+                         const uint16_t *records, uint8_t *bytes, cabac_substream_result *results);
+hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
+                         const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
+                         cabac_substream_result *results);
+
+}  // namespace cabac
+#endif

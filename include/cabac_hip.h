@@ -1,0 +1,205 @@
+/*
+ * cabac_hip.h — C ABI of the MI355X-native CABAC bin codec (libcabac_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of p-sawicki/entropy_coding:
+ * the arithmetic bin encoder/decoder + context model + binarisation helpers
+ * (reference: src/entropy_codec/arith_codec.{hpp,cpp}, src/common/contexts.{hpp,cpp},
+ * src/common/bit_stream.{hpp,cpp}, cabac_writer.cpp:854-882,3072-3118).
+ *
+ * The reference drives the codec through ~10^5 tiny virtual calls per frame
+ * (BinEncIf, arith_codec.hpp:31-70).  Those cannot cross a device boundary one
+ * at a time, so the boundary is *batched*: host code records the calls of one
+ * independent CABAC substream (slice / tile / frame) as a flat array of 16-bit
+ * bin records, and a batch of substreams is coded on the GPU — one wavefront
+ * per substream.  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * All functions return 0 (CABAC_HIP_OK) or a negative cabac_hip_status.
+ * No exception crosses this boundary.  A cabac_hip_ctx is bound to one device
+ * and one HIP stream; calls on the same ctx must not overlap, different ctxs
+ * are independent (thread-safe per ctx).
+ */
+#ifndef CABAC_HIP_H
+#define CABAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Constants of the codec (reference: contexts.cpp:773-774, type_def.hpp:21-26) */
+#define CABAC_NUM_CONTEXTS 379 /* Ctx::NumberOfContexts                       */
+#define CABAC_INIT_B 0         /* B_SLICE init table                          */
+#define CABAC_INIT_P 1         /* P_SLICE                                     */
+#define CABAC_INIT_I 2         /* I_SLICE                                     */
+
+/* ------------------------------------------------------------------ */
+/* Bin record (uint16_t) — one per coded bin.
+ *   bit 15     bin value (encode input; ignored on decode input)
+ *   bits 14..9 zero
+ *   bits 8..0  id: 0..378 = context-coded bin with that ctxId
+ *                  (BinEncIf::encodeBin(bin, ctxId), arith_codec.cpp:553-582)
+ *              0x1FE = bypass bin   (encodeBinEP,  arith_codec.cpp:389-399)
+ *              0x1FF = terminate bin(encodeBinTrm, arith_codec.cpp:460-478)
+ *              0x1FD = align(): range := 256 (arith_codec.cpp:480); codes no bin
+ * encodeBinsEP / encodeRemAbsEP (arith_codec.cpp:401-458) are recorded as their
+ * individual bypass bins, MSB first — byte-identical by construction (the
+ * reference's 8-at-a-time loop is arithmetically n single bypass bins).
+ */
+#define CABAC_REC_BIN 0x8000u
+#define CABAC_REC_ID_MASK 0x01FFu
+#define CABAC_REC_ALIGN 0x01FDu
+#define CABAC_REC_EP 0x01FEu
+#define CABAC_REC_TRM 0x01FFu
+
+/* ------------------------------------------------------------------ */
+/* Syntax-element record (2 x uint32_t) — input of the device binariser
+ * (cabac_hip_binarize_device).  word0 = kind | params, word1 = value.
+ *   kind (bits 3..0 of word0):
+ *     0 CTX_BIN     p: ctxId[12:4]                       value = bin
+ *     1 EP_BINS     p: numBins[9:4] (0..32)              value = bins, MSB first
+ *                   (BinEncIf::encodeBinsEP, arith_codec.cpp:401-424)
+ *     2 REM_ABS     p: rice[8:4], cutoff[13:9], maxLog2TrDR[19:14]
+ *                   (BinEncIf::encodeRemAbsEP, arith_codec.cpp:426-458)
+ *     3 TRM         value = bin   (encodeBinTrm)
+ *     4 UNARY_MAX   p: ctxId0[12:4], ctxIdN[21:13], maxSymbol[29:22]
+ *                   (CABACWriter::unary_max_symbol, cabac_writer.cpp:3072-3081)
+ *     5 UNARY_EP    p: maxSymbol[9:4] (<=32)
+ *                   (CABACWriter::unary_max_eqprob, cabac_writer.cpp:3083-3101)
+ *     6 EXP_GOLOMB  p: count[8:4]
+ *                   (CABACWriter::exp_golomb_eqprob, cabac_writer.cpp:3103-3118)
+ *     7 TRUNC_BIN   p: maxSymbol[31:4]
+ *                   (CABACWriter::xWriteTruncBinCode, cabac_writer.cpp:854-882)
+ *     8 ALIGN
+ */
+#define CABAC_SE_CTX_BIN 0u
+#define CABAC_SE_EP_BINS 1u
+#define CABAC_SE_REM_ABS 2u
+#define CABAC_SE_TRM 3u
+#define CABAC_SE_UNARY_MAX 4u
+#define CABAC_SE_UNARY_EP 5u
+#define CABAC_SE_EXP_GOLOMB 6u
+#define CABAC_SE_TRUNC_BIN 7u
+#define CABAC_SE_ALIGN 8u
+
+/* ------------------------------------------------------------------ */
+/* One independent CABAC substream (private context store, private low/range,
+ * private byte stream; reference: cabac_writer.cpp:16-39, :104-107).        */
+typedef struct cabac_substream_desc {
+  uint64_t rec_offset;    /* first record of this substream in records[] (in records) */
+  uint64_t byte_offset;   /* first byte of this substream in bytes[]                 */
+  uint32_t n_records;     /* number of bin records                                    */
+  uint32_t byte_capacity; /* encode: room at byte_offset; decode: valid input bytes   */
+  int32_t qp;             /* slice QP for Ctx::init (clipped to 0..63, contexts.cpp:1010) */
+  uint32_t init_id;       /* bits 1..0: CABAC_INIT_B/P/I;  bits 31..8: CABAC_SUB_* flags */
+} cabac_substream_desc;
+
+/* desc.init_id flag bits */
+#define CABAC_SUB_FINISH 0x100u /* encode: run BinEncoderBase::finish() (arith_codec.cpp:339-357) \
+                                   decode: run BinDecoderBase::finish() stop-pattern check (:68-73) */
+#define CABAC_SUB_ALIGN_RBSP 0x200u /* encode, with FINISH: also OutputBitstream::writeByteAlignment() \
+                                       (bit_stream.cpp:152-155): stop bit '1' + zero pad            */
+
+typedef struct cabac_substream_result {
+  uint32_t n_bits; /* encode: bits written (8*whole bytes + held bits, i.e.
+                      OutputBitstream::getNumberOfWrittenBits(), bit_stream.cpp:60-62);
+                      a trailing partial byte is MSB-aligned, zero padded.
+                      decode: 8*bytes consumed + bitsNeeded (getNumBitsRead analogue) */
+  uint32_t flags;  /* CABAC_RES_* */
+} cabac_substream_result;
+
+#define CABAC_RES_OVERFLOW 0x1u    /* encode: byte_capacity too small (output truncated)     */
+#define CABAC_RES_BAD_RECORD 0x2u  /* record id is neither a ctxId < 379 nor a special id    */
+#define CABAC_RES_UNDERRUN 0x4u    /* decode: read past byte_capacity ("FIFO exceeded",      \
+                                      bit_stream.cpp:269)                                    */
+#define CABAC_RES_BAD_STOP 0x8u    /* decode: finish() stop/alignment pattern check failed   */
+
+typedef enum cabac_hip_status {
+  CABAC_HIP_OK = 0,
+  CABAC_HIP_ERR_NO_DEVICE = -1,
+  CABAC_HIP_ERR_INVALID = -2,
+  CABAC_HIP_ERR_HIP = -3,      /* a HIP runtime call failed; see cabac_hip_last_error */
+  CABAC_HIP_ERR_NOMEM = -4,
+  CABAC_HIP_ERR_SUBSTREAM = -5 /* at least one substream result has a flag set       */
+} cabac_hip_status;
+
+typedef struct cabac_hip_ctx cabac_hip_ctx;
+
+/* Worst-case encoded size in bytes of a substream with the given bin counts
+ * (a context bin shifts out <= 6 bits, contexts.cpp:787-789; bypass 1;
+ * terminate <= 7; finish() <= 3 bytes + alignment).                          */
+size_t cabac_hip_encode_bound(uint64_t n_ctx_bins, uint64_t n_ep_bins, uint64_t n_trm_bins);
+
+/* ---- lifetime ----------------------------------------------------- */
+/* device: HIP device ordinal.  Fails (CABAC_HIP_ERR_NO_DEVICE) when no GPU is
+ * present: there is no CPU fallback in this library.                         */
+int cabac_hip_init(int device, cabac_hip_ctx **out);
+void cabac_hip_destroy(cabac_hip_ctx *ctx);
+const char *cabac_hip_strerror(int status);
+const char *cabac_hip_last_error(const cabac_hip_ctx *ctx);
+/* Adopt an existing HIP stream (hipStream_t passed as void*; NULL = ctx's own) */
+int cabac_hip_set_stream(cabac_hip_ctx *ctx, void *hip_stream);
+int cabac_hip_synchronize(cabac_hip_ctx *ctx);
+/* kernel variant: 0 = default (fastest verified), others are listed in DESIGN.md */
+int cabac_hip_set_variant(cabac_hip_ctx *ctx, int encode_variant, int decode_variant);
+
+/* ---- device-pointer entry points (asynchronous on the ctx stream) ---
+ * Replace: BinEncoderBase::reset/start + TBinEncoder::encodeBin + encodeBinEP +
+ * encodeBinTrm + writeOut + finish (arith_codec.cpp:329-357, :367-370, :389-399,
+ * :460-478, :524-582) and Ctx::init (contexts.cpp:996-1015, :1133-1145) for a
+ * batch of n_sub substreams.  All pointers are device memory.                */
+int cabac_hip_encode_device(cabac_hip_ctx *ctx, uint32_t n_sub,
+                            const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                            uint8_t *d_bytes, cabac_substream_result *d_results);
+
+/* Replace: BinDecoderBase::reset/start + TBinDecoder::decodeBin + decodeBinEP +
+ * decodeBinTrm + finish (arith_codec.cpp:60-78, :100-114, :181-197, :242-277).
+ * d_records supplies the ctxId / EP / TRM sequence (bin bit ignored);
+ * d_bins[rec_offset + i] receives the decoded bin (0/1) of record i.         */
+int cabac_hip_decode_device(cabac_hip_ctx *ctx, uint32_t n_sub,
+                            const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                            const uint8_t *d_bytes, uint8_t *d_bins,
+                            cabac_substream_result *d_results);
+
+/* Context-store initialisation only (Ctx::init, contexts.cpp:893-901, :915-920,
+ * :996-1015): d_state[(s*379 + k)] = s0 | s1 << 16, d_rate[...] = m_rate for
+ * substream s = (qp[s], init_id[s]).  Used by parity tests.                  */
+int cabac_hip_ctx_init_device(cabac_hip_ctx *ctx, uint32_t n_sub, const int32_t *d_qp,
+                              const uint32_t *d_init_id, uint32_t *d_state, uint8_t *d_rate);
+
+/* Device binariser: syntax-element records -> bin records (the binarisation
+ * helpers listed at the SE record format above).  d_se_offset has n_sub+1
+ * entries delimiting each substream's SE records.  Pass 1 (d_records == NULL)
+ * only writes d_n_records[s]; pass 2 writes the records at d_rec_offset[s].   */
+int cabac_hip_binarize_device(cabac_hip_ctx *ctx, uint32_t n_sub, const uint64_t *d_se_offset,
+                              const uint32_t *d_se, const uint64_t *d_rec_offset,
+                              uint32_t *d_n_records, uint16_t *d_records);
+
+/* ---- host-pointer convenience (synchronous; pinned staging inside) --- */
+int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                           const uint16_t *records, uint64_t n_records_total, uint8_t *bytes,
+                           uint64_t bytes_total, cabac_substream_result *results);
+int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                           const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
+                           uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
+
+/* ---- timing of the last device call (HIP events on the ctx stream) --- */
+/* milliseconds between the events that bracket the kernel(s) of the last
+ * encode/decode/binarize device call; <0 if unavailable.  Synchronises.      */
+float cabac_hip_last_kernel_ms(cabac_hip_ctx *ctx);
+
+/* ---- synthetic workload generator (host, deterministic) ---------------
+ * The residual-heavy bin mix of SURVEY.md §8(d): SplitMix64 seeded with
+ * seed ^ substream_index; ctx_permille of the bins context coded (60 % of them
+ * from ctxIds 90..245, 15 % from 246..291, 25 % uniform over the rest, each
+ * context with a fixed P(1) out of {0.03,0.1,0.25,0.5,0.75,0.9}); the rest fair
+ * bypass bins; the last record is TRM(1).  Writes n_bins records.            */
+void cabac_synth_records(uint64_t seed, uint64_t substream_index, uint32_t n_bins,
+                         uint32_t ctx_permille, uint16_t *out_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CABAC_HIP_H */

@@ -1,0 +1,811 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See cabac_oracle.h for the status header.
+ *
+ * Plain-C restatement of the reference's CABAC bin codec (VVC clause 9.3.4), written in this
+ * repository's own idiom (flat POD state, SoA context store, one bit-packer).  Every function
+ * cites the reference lines it follows; paths are relative to /root/reference/src.
+ */
+#include "cabac_oracle.h"
+
+#include <string.h>
+
+#include "cabac_ctx_tables.h"
+#include "cabac_hip.h"
+
+/* ---------------------------------------------------------------- tables */
+static const uint8_t k_init_flat[CABAC_CTX_TABLE_ROWS * CABAC_CTX_TABLE_COLS] = {CABAC_CTX_INIT_TABLE_VALUES};
+#define k_init(row, k) k_init_flat[(row) * CABAC_CTX_TABLE_COLS + (k)]
+
+/* common/contexts.hpp:12-21 */
+enum { MASK_0 = 0x7FE0, MASK_1 = 0x7FFE };
+
+/* ---------------------------------------------------------------- context model */
+typedef struct {
+  uint16_t s0[ORC_NUM_CTX];
+  uint16_t s1[ORC_NUM_CTX];
+  uint8_t rate[ORC_NUM_CTX];
+} ctx_store;
+
+/* BinProbModel_Std::init, common/contexts.cpp:893-901;
+ * setLog2WindowSize, :915-920; CtxStore::init (QP clip 0..63), :996-1015 */
+static void ctx_store_init(ctx_store *c, int qp, int init_id) {
+  if (qp < 0) qp = 0;
+  if (qp > 63) qp = 63;
+  for (int k = 0; k < ORC_NUM_CTX; k++) {
+    int iv = k_init(init_id, k);
+    int slope = (iv >> 3) - 4;
+    int offset = (iv & 7) * 18 + 1;
+    int st = ((slope * (qp - 16)) >> 1) + offset;
+    if (st < 1) st = 1;
+    if (st > 127) st = 127;
+    int p1 = st << 8;
+    c->s0[k] = (uint16_t)(p1 & MASK_0);
+    c->s1[k] = (uint16_t)(p1 & MASK_1);
+    int w = k_init(3, k);
+    int r0 = 2 + ((w >> 2) & 3);
+    int r1 = 3 + r0 + (w & 3);
+    c->rate[k] = (uint8_t)(16 * r0 + r1);
+  }
+}
+
+/* state(): contexts.cpp:939-941 — 8-bit truncation is semantic */
+static inline unsigned ctx_state8(const ctx_store *c, unsigned k) {
+  return ((unsigned)(c->s0[k] + c->s1[k]) >> 8) & 0xff;
+}
+
+/* getLPS(range): contexts.cpp:945-950 (returns uint8_t) */
+static inline unsigned ctx_lps(unsigned state8, unsigned range) {
+  unsigned q = state8;
+  if (q & 0x80) q ^= 0xff;
+  return ((((q >> 2) * (range >> 5)) >> 1) + 4) & 0xff;
+}
+
+/* update(bin): contexts.cpp:903-913 */
+static inline void ctx_update(ctx_store *c, unsigned k, unsigned bin) {
+  int r0 = c->rate[k] >> 4, r1 = c->rate[k] & 15;
+  uint16_t a = c->s0[k], b = c->s1[k];
+  a = (uint16_t)(a - ((a >> r0) & MASK_0));
+  b = (uint16_t)(b - ((b >> r1) & MASK_1));
+  if (bin) {
+    a = (uint16_t)(a + ((0x7fffu >> r0) & MASK_0));
+    b = (uint16_t)(b + ((0x7fffu >> r1) & MASK_1));
+  }
+  c->s0[k] = a;
+  c->s1[k] = b;
+}
+
+/* getRenormBitsLPS: contexts.cpp:952-954 with m_RenormTable_32 (:787-789) */
+static const uint8_t k_renorm[32] = {6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2,
+                                     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+
+void orc_ctx_init(int qp, int init_id, uint16_t *s0, uint16_t *s1, uint8_t *rate) {
+  ctx_store c;
+  ctx_store_init(&c, qp, init_id);
+  memcpy(s0, c.s0, sizeof c.s0);
+  memcpy(s1, c.s1, sizeof c.s1);
+  memcpy(rate, c.rate, sizeof c.rate);
+}
+
+void orc_ctx_trace(int qp, int init_id, int ctx_id, const uint8_t *bins, int n, unsigned range,
+                   uint8_t *state8, uint8_t *lps, uint16_t *s0_after, uint16_t *s1_after) {
+  ctx_store c;
+  ctx_store_init(&c, qp, init_id);
+  for (int i = 0; i < n; i++) {
+    unsigned q = ctx_state8(&c, (unsigned)ctx_id);
+    state8[i] = (uint8_t)q;
+    lps[i] = (uint8_t)ctx_lps(q, range);
+    ctx_update(&c, (unsigned)ctx_id, bins[i]);
+    s0_after[i] = c.s0[ctx_id];
+    s1_after[i] = c.s1[ctx_id];
+  }
+}
+
+/* ---------------------------------------------------------------- output bit packer
+ * Observable behaviour of OutputBitstream::write / writeAlignZero / writeByteAlignment
+ * (common/bit_stream.cpp:70-117, :125-132, :152-155): MSB-first packing, whole bytes to
+ * the FIFO, < 8 bits held MSB-aligned. */
+typedef struct {
+  uint8_t *buf;
+  long cap, n;    /* whole bytes */
+  unsigned held;  /* MSB-aligned held bits */
+  unsigned nheld; /* 0..7 */
+  int overflow;
+} bit_sink;
+
+static void sink_put(bit_sink *s, uint32_t bits, unsigned nbits) {
+  for (int i = (int)nbits - 1; i >= 0; i--) {
+    s->held |= ((bits >> i) & 1u) << (7 - s->nheld);
+    if (++s->nheld == 8) {
+      if (s->n < s->cap) s->buf[s->n] = (uint8_t)s->held;
+      else s->overflow = 1;
+      s->n++;
+      s->held = 0;
+      s->nheld = 0;
+    }
+  }
+}
+
+static inline void sink_byte(bit_sink *s, unsigned b) { sink_put(s, b & 0xff, 8); }
+
+/* ---------------------------------------------------------------- bin encoder */
+typedef struct {
+  ctx_store ctx;
+  uint32_t low, range, buffered_byte;
+  int32_t num_buffered, bits_left;
+  uint32_t n_ctx, n_ep, n_trm; /* BinCounter, entropy_codec/arith_codec.cpp:281-316 */
+  bit_sink *out;
+} bin_enc;
+
+/* BinEncoderBase::start, arith_codec.cpp:329-337 */
+static void enc_start(bin_enc *e) {
+  e->low = 0;
+  e->range = 510;
+  e->buffered_byte = 0xff;
+  e->num_buffered = 0;
+  e->bits_left = 23;
+  e->n_ctx = e->n_ep = e->n_trm = 0;
+}
+
+/* BinEncoderBase::writeOut, arith_codec.cpp:524-546 */
+static void enc_write_out(bin_enc *e) {
+  unsigned lead = e->low >> (24 - e->bits_left);
+  e->bits_left += 8;
+  e->low &= 0xffffffffu >> e->bits_left;
+  if (lead == 0xff) {
+    e->num_buffered++;
+  } else if (e->num_buffered > 0) {
+    unsigned carry = lead >> 8;
+    unsigned byte = e->buffered_byte + carry;
+    e->buffered_byte = lead & 0xff;
+    sink_byte(e->out, byte);
+    byte = (0xff + carry) & 0xff;
+    while (e->num_buffered > 1) {
+      sink_byte(e->out, byte);
+      e->num_buffered--;
+    }
+  } else {
+    e->num_buffered = 1;
+    e->buffered_byte = lead;
+  }
+}
+
+/* TBinEncoder::encodeBin, arith_codec.cpp:553-582 */
+static void enc_bin(bin_enc *e, unsigned bin, unsigned ctx_id) {
+  e->n_ctx++;
+  unsigned q = ctx_state8(&e->ctx, ctx_id);
+  unsigned lps = ctx_lps(q, e->range);
+  e->range -= lps;
+  if (bin != (q >> 7)) {
+    int nb = k_renorm[lps >> 3];
+    e->bits_left -= nb;
+    e->low += e->range;
+    e->low <<= nb;
+    e->range = lps << nb;
+    if (e->bits_left < 12) enc_write_out(e);
+  } else if (e->range < 256) {
+    e->bits_left -= 1;
+    e->low <<= 1;
+    e->range <<= 1;
+    if (e->bits_left < 12) enc_write_out(e);
+  }
+  ctx_update(&e->ctx, ctx_id, bin);
+}
+
+/* encodeBinEP, arith_codec.cpp:389-399 */
+static void enc_ep(bin_enc *e, unsigned bin) {
+  e->n_ep++;
+  e->low <<= 1;
+  if (bin) e->low += e->range;
+  e->bits_left--;
+  if (e->bits_left < 12) enc_write_out(e);
+}
+
+/* encodeBinsEP incl. the range==256 branch (encodeAlignedBinsEP), arith_codec.cpp:401-424,
+ * :491-522.  Follows the reference's 8-at-a-time arithmetic literally (so that a `bins`
+ * value with stray high bits behaves as it does there). */
+static void enc_bins_ep(bin_enc *e, unsigned bins, unsigned n) {
+  e->n_ep += n;
+  if (e->range == 256) {
+    unsigned rem = n;
+    while (rem > 0) {
+      unsigned k = rem < 8 ? rem : 8;
+      unsigned mask = (1u << k) - 1;
+      unsigned nb = (bins >> (rem - k)) & mask;
+      e->low = (e->low << k) + (nb << 8);
+      rem -= k;
+      e->bits_left -= (int)k;
+      if (e->bits_left < 12) enc_write_out(e);
+    }
+    return;
+  }
+  while (n > 8) {
+    n -= 8;
+    unsigned pattern = bins >> n;
+    e->low <<= 8;
+    e->low += e->range * pattern;
+    bins -= pattern << n;
+    e->bits_left -= 8;
+    if (e->bits_left < 12) enc_write_out(e);
+  }
+  e->low <<= n;
+  e->low += e->range * bins;
+  e->bits_left -= (int)n;
+  if (e->bits_left < 12) enc_write_out(e);
+}
+
+/* encodeRemAbsEP, arith_codec.cpp:426-458 */
+static void enc_rem_abs(bin_enc *e, unsigned v, unsigned rice, unsigned cutoff, int max_log2) {
+  const unsigned threshold = cutoff << rice;
+  if (v < threshold) {
+    const unsigned mask = (1u << rice) - 1;
+    const unsigned length = (v >> rice) + 1;
+    enc_bins_ep(e, (1u << length) - 2, length);
+    enc_bins_ep(e, v & mask, rice);
+  } else {
+    const unsigned max_prefix = 32 - cutoff - (unsigned)max_log2;
+    unsigned prefix_len = 0, suffix_len;
+    unsigned code = (v >> rice) - cutoff;
+    if (code >= ((1u << max_prefix) - 1)) {
+      prefix_len = max_prefix;
+      suffix_len = (unsigned)max_log2;
+    } else {
+      while (code > ((2u << prefix_len) - 2u)) prefix_len++;
+      suffix_len = prefix_len + rice + 1;
+    }
+    const unsigned total_prefix = prefix_len + cutoff;
+    const unsigned mask = (1u << rice) - 1;
+    const unsigned prefix = (1u << total_prefix) - 1;
+    const unsigned suffix = ((code - ((1u << prefix_len) - 1)) << rice) | (v & mask);
+    enc_bins_ep(e, prefix, total_prefix);
+    enc_bins_ep(e, suffix, suffix_len);
+  }
+}
+
+/* encodeBinTrm, arith_codec.cpp:460-478 */
+static void enc_trm(bin_enc *e, unsigned bin) {
+  e->n_trm++;
+  e->range -= 2;
+  if (bin) {
+    e->low += e->range;
+    e->low <<= 7;
+    e->range = 2 << 7;
+    e->bits_left -= 7;
+  } else if (e->range >= 256) {
+    return;
+  } else {
+    e->low <<= 1;
+    e->range <<= 1;
+    e->bits_left--;
+  }
+  if (e->bits_left < 12) enc_write_out(e);
+}
+
+/* finish, arith_codec.cpp:339-357 */
+static void enc_finish(bin_enc *e) {
+  if (e->low >> (32 - e->bits_left)) {
+    sink_byte(e->out, e->buffered_byte + 1);
+    while (e->num_buffered > 1) {
+      sink_byte(e->out, 0x00);
+      e->num_buffered--;
+    }
+    e->low -= 1u << (32 - e->bits_left);
+  } else {
+    if (e->num_buffered > 0) sink_byte(e->out, e->buffered_byte);
+    while (e->num_buffered > 1) {
+      sink_byte(e->out, 0xff);
+      e->num_buffered--;
+    }
+  }
+  sink_put(e->out, e->low >> 8, (unsigned)(24 - e->bits_left));
+}
+
+/* ---------------------------------------------------------------- binarisation helpers */
+static unsigned floor_log2(unsigned x) {
+  unsigned r = 0;
+  while (x >>= 1) r++;
+  return r;
+}
+
+/* CABACWriter::unary_max_symbol, entropy_codec/cabac_writer.cpp:3072-3081 */
+static int bz_unary_max(bin_enc *e, unsigned symbol, unsigned c0, unsigned cn, unsigned max_symbol) {
+  if (symbol > max_symbol) return -2;
+  unsigned total = symbol + 1 < max_symbol ? symbol + 1 : max_symbol;
+  for (unsigned k = 0; k < total; k++) enc_bin(e, symbol > k, k == 0 ? c0 : cn);
+  return 0;
+}
+
+/* unary_max_eqprob, cabac_writer.cpp:3083-3101 */
+static int bz_unary_ep(bin_enc *e, unsigned symbol, unsigned max_symbol) {
+  if (max_symbol == 0) return 0;
+  int code_last = max_symbol > symbol;
+  unsigned bins = 0, n = 0;
+  while (symbol--) {
+    bins = (bins << 1) + 1;
+    n++;
+  }
+  if (code_last) {
+    bins <<= 1;
+    n++;
+  }
+  if (n > 32) return -2;
+  enc_bins_ep(e, bins, n);
+  return 0;
+}
+
+/* exp_golomb_eqprob, cabac_writer.cpp:3103-3118 */
+static void bz_exp_golomb(bin_enc *e, unsigned symbol, unsigned count) {
+  unsigned bins = 0, n = 0;
+  while (symbol >= (1u << count)) {
+    bins = (bins << 1) + 1;
+    n++;
+    symbol -= 1u << count;
+    count++;
+  }
+  bins <<= 1;
+  n++;
+  enc_bins_ep(e, bins, n);
+  enc_bins_ep(e, symbol, count);
+}
+
+/* xWriteTruncBinCode, cabac_writer.cpp:854-882 (g_tbMax[k] == floor(log2 k), rom.hpp:43-54) */
+static void bz_trunc_bin(bin_enc *e, unsigned symbol, unsigned max_symbol) {
+  unsigned thresh = floor_log2(max_symbol);
+  unsigned val = 1u << thresh;
+  unsigned b = max_symbol - val;
+  if (symbol < val - b) {
+    enc_bins_ep(e, symbol, thresh);
+  } else {
+    symbol += val - b;
+    enc_bins_ep(e, symbol, thresh + 1);
+  }
+}
+
+/* ---------------------------------------------------------------- encode drivers */
+static long finish_stream(bin_enc *e, bit_sink *s, int flags, uint32_t *n_bits) {
+  if (flags & 1) enc_finish(e);
+  if (flags & 2) { /* writeByteAlignment, bit_stream.cpp:152-155 */
+    sink_put(s, 1, 1);
+    if (s->nheld) sink_put(s, 0, 8 - s->nheld);
+  }
+  *n_bits = (uint32_t)(s->n * 8 + s->nheld);
+  long total = s->n + (s->nheld ? 1 : 0);
+  if (s->overflow || total > s->cap) return -3;
+  if (s->nheld) s->buf[s->n] = (uint8_t)s->held;
+  return total;
+}
+
+long orc_encode_ops(const uint32_t *ops, long n_ops, int qp, int init_id, int flags, uint8_t *out,
+                    long cap, uint32_t *n_bits, uint32_t *n_bins_out) {
+  bit_sink s = {out, cap, 0, 0, 0, 0};
+  bin_enc e;
+  e.out = &s;
+  ctx_store_init(&e.ctx, qp, init_id);
+  enc_start(&e);
+  for (long i = 0; i < n_ops; i++) {
+    const uint32_t *o = ops + 4 * i;
+    int rc = 0;
+    switch (o[0]) {
+    case ORC_OP_ENC_BIN:
+      if (o[2] >= ORC_NUM_CTX) return -2;
+      enc_bin(&e, o[1], o[2]);
+      break;
+    case ORC_OP_ENC_EP: enc_ep(&e, o[1]); break;
+    case ORC_OP_ENC_BINS_EP: enc_bins_ep(&e, o[1], o[2]); break;
+    case ORC_OP_ENC_REM_ABS: enc_rem_abs(&e, o[1], o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+    case ORC_OP_ENC_TRM: enc_trm(&e, o[1]); break;
+    case ORC_OP_ALIGN: e.range = 256; break; /* align(), arith_codec.cpp:480 */
+    case ORC_OP_UNARY_MAX: rc = bz_unary_max(&e, o[1], o[2] & 0xffff, o[2] >> 16, o[3]); break;
+    case ORC_OP_UNARY_EP: rc = bz_unary_ep(&e, o[1], o[2]); break;
+    case ORC_OP_EXP_GOLOMB: bz_exp_golomb(&e, o[1], o[2]); break;
+    case ORC_OP_TRUNC_BIN: bz_trunc_bin(&e, o[1], o[2]); break;
+    default: return -2;
+    }
+    if (rc) return rc;
+  }
+  if (n_bins_out) {
+    n_bins_out[0] = e.n_ctx;
+    n_bins_out[1] = e.n_ep;
+    n_bins_out[2] = e.n_trm;
+  }
+  return finish_stream(&e, &s, flags, n_bits);
+}
+
+static int encode_record_run(bin_enc *e, const uint16_t *rec, long n) {
+  for (long i = 0; i < n; i++) {
+    unsigned id = rec[i] & CABAC_REC_ID_MASK, bin = rec[i] >> 15;
+    if (id < ORC_NUM_CTX) enc_bin(e, bin, id);
+    else if (id == CABAC_REC_EP) enc_ep(e, bin);
+    else if (id == CABAC_REC_TRM) enc_trm(e, bin);
+    else if (id == CABAC_REC_ALIGN) e->range = 256;
+    else return -2;
+  }
+  return 0;
+}
+
+long orc_encode_records(const uint16_t *rec, long n, int qp, int init_id, int flags, uint8_t *out,
+                        long cap, uint32_t *n_bits) {
+  bit_sink s = {out, cap, 0, 0, 0, 0};
+  bin_enc e;
+  e.out = &s;
+  ctx_store_init(&e.ctx, qp, init_id);
+  enc_start(&e);
+  if (encode_record_run(&e, rec, n)) return -2;
+  return finish_stream(&e, &s, flags, n_bits);
+}
+
+/* ---------------------------------------------------------------- ops -> records */
+typedef struct {
+  uint16_t *rec;
+  long cap, n;
+} rec_sink;
+
+static void rs_put(rec_sink *r, unsigned id, unsigned bin) {
+  if (r->rec && r->n < r->cap) r->rec[r->n] = (uint16_t)(id | (bin ? CABAC_REC_BIN : 0));
+  r->n++;
+}
+static void rs_bins_ep(rec_sink *r, unsigned bins, unsigned n) {
+  for (int i = (int)n - 1; i >= 0; i--) rs_put(r, CABAC_REC_EP, (bins >> i) & 1);
+}
+
+long orc_ops_to_records(const uint32_t *ops, long n_ops, uint16_t *rec, long cap) {
+  rec_sink r = {rec, cap, 0};
+  for (long i = 0; i < n_ops; i++) {
+    const uint32_t *o = ops + 4 * i;
+    switch (o[0]) {
+    case ORC_OP_ENC_BIN: rs_put(&r, o[2], o[1]); break;
+    case ORC_OP_ENC_EP: rs_put(&r, CABAC_REC_EP, o[1]); break;
+    case ORC_OP_ENC_BINS_EP: rs_bins_ep(&r, o[1], o[2]); break;
+    case ORC_OP_ENC_REM_ABS: { /* arith_codec.cpp:426-458 */
+      unsigned v = o[1], rice = o[2], cutoff = o[3] & 0xff;
+      int max_log2 = (int)(o[3] >> 8);
+      if (v < (cutoff << rice)) {
+        unsigned length = (v >> rice) + 1;
+        rs_bins_ep(&r, (1u << length) - 2, length);
+        rs_bins_ep(&r, v & ((1u << rice) - 1), rice);
+      } else {
+        unsigned max_prefix = 32 - cutoff - (unsigned)max_log2, pl = 0, sl;
+        unsigned code = (v >> rice) - cutoff;
+        if (code >= ((1u << max_prefix) - 1)) {
+          pl = max_prefix;
+          sl = (unsigned)max_log2;
+        } else {
+          while (code > ((2u << pl) - 2u)) pl++;
+          sl = pl + rice + 1;
+        }
+        rs_bins_ep(&r, (1u << (pl + cutoff)) - 1, pl + cutoff);
+        rs_bins_ep(&r, ((code - ((1u << pl) - 1)) << rice) | (v & ((1u << rice) - 1)), sl);
+      }
+      break;
+    }
+    case ORC_OP_ENC_TRM: rs_put(&r, CABAC_REC_TRM, o[1]); break;
+    case ORC_OP_ALIGN: rs_put(&r, CABAC_REC_ALIGN, 0); break;
+    case ORC_OP_UNARY_MAX: { /* cabac_writer.cpp:3072-3081 */
+      unsigned symbol = o[1], c0 = o[2] & 0xffff, cn = o[2] >> 16, mx = o[3];
+      if (symbol > mx) return -2;
+      unsigned total = symbol + 1 < mx ? symbol + 1 : mx;
+      for (unsigned k = 0; k < total; k++) rs_put(&r, k == 0 ? c0 : cn, symbol > k);
+      break;
+    }
+    case ORC_OP_UNARY_EP: { /* cabac_writer.cpp:3083-3101 */
+      unsigned symbol = o[1], mx = o[2];
+      if (mx == 0) break;
+      for (unsigned k = 0; k < symbol; k++) rs_put(&r, CABAC_REC_EP, 1);
+      if (mx > symbol) rs_put(&r, CABAC_REC_EP, 0);
+      break;
+    }
+    case ORC_OP_EXP_GOLOMB: { /* cabac_writer.cpp:3103-3118 */
+      unsigned symbol = o[1], count = o[2];
+      while (symbol >= (1u << count)) {
+        rs_put(&r, CABAC_REC_EP, 1);
+        symbol -= 1u << count;
+        count++;
+      }
+      rs_put(&r, CABAC_REC_EP, 0);
+      rs_bins_ep(&r, symbol, count);
+      break;
+    }
+    case ORC_OP_TRUNC_BIN: { /* cabac_writer.cpp:854-882 */
+      unsigned symbol = o[1], mx = o[2];
+      unsigned thresh = floor_log2(mx), val = 1u << thresh, b = mx - val;
+      if (symbol < val - b) rs_bins_ep(&r, symbol, thresh);
+      else rs_bins_ep(&r, symbol + val - b, thresh + 1);
+      break;
+    }
+    default: return -2;
+    }
+  }
+  return r.n;
+}
+
+/* ---------------------------------------------------------------- bin decoder */
+typedef struct {
+  ctx_store ctx;
+  uint32_t range, value;
+  int32_t bits_needed;
+  const uint8_t *in;
+  long n_in, idx;
+  int underrun;
+} bin_dec;
+
+/* InputBitstream::readByte, common/bit_stream.cpp:268-274 (CHECK "FIFO exceeded") */
+static inline unsigned dec_read_byte(bin_dec *d) {
+  if (d->idx >= d->n_in) {
+    d->underrun = 1;
+    d->idx++;
+    return 0;
+  }
+  return d->in[d->idx++];
+}
+
+/* BinDecoderBase::start, arith_codec.cpp:60-66 */
+static void dec_start(bin_dec *d) {
+  d->range = 510;
+  unsigned b0 = dec_read_byte(d);
+  unsigned b1 = dec_read_byte(d);
+  d->value = (b0 << 8) + b1;
+  d->bits_needed = -8;
+}
+
+/* TBinDecoder::decodeBin, arith_codec.cpp:242-277 */
+static unsigned dec_bin(bin_dec *d, unsigned ctx_id) {
+  unsigned q = ctx_state8(&d->ctx, ctx_id);
+  unsigned bin = q >> 7;
+  unsigned lps = ctx_lps(q, d->range);
+  d->range -= lps;
+  uint32_t sr = d->range << 7;
+  if (d->value < sr) {
+    if (d->range < 256) {
+      d->range <<= 1;
+      d->value <<= 1;
+      d->bits_needed += 1;
+      if (d->bits_needed >= 0) {
+        d->value += dec_read_byte(d) << d->bits_needed;
+        d->bits_needed -= 8;
+      }
+    }
+  } else {
+    bin = 1 - bin;
+    int nb = k_renorm[lps >> 3];
+    d->value -= sr;
+    d->value <<= nb;
+    d->range = lps << nb;
+    d->bits_needed += nb;
+    if (d->bits_needed >= 0) {
+      d->value += dec_read_byte(d) << d->bits_needed;
+      d->bits_needed -= 8;
+    }
+  }
+  ctx_update(&d->ctx, ctx_id, bin);
+  return bin;
+}
+
+/* decodeBinEP, arith_codec.cpp:100-114 */
+static unsigned dec_ep(bin_dec *d) {
+  d->value += d->value;
+  if (++d->bits_needed >= 0) {
+    d->value += dec_read_byte(d);
+    d->bits_needed = -8;
+  }
+  unsigned sr = d->range << 7;
+  if (d->value >= sr) {
+    d->value -= sr;
+    return 1;
+  }
+  return 0;
+}
+
+/* decodeBinsEP (+ decodeAlignedBinsEP), arith_codec.cpp:116-151, :205-235 */
+static unsigned dec_bins_ep(bin_dec *d, unsigned n) {
+  unsigned bins = 0;
+  if (d->range == 256) {
+    unsigned rem = n;
+    while (rem > 0) {
+      unsigned k = rem < 8 ? rem : 8;
+      unsigned mask = (1u << k) - 1;
+      unsigned nb = (d->value >> (15 - k)) & mask;
+      bins = (bins << k) | nb;
+      d->value = (d->value << k) & 0x7FFF;
+      rem -= k;
+      d->bits_needed += (int)k;
+      if (d->bits_needed >= 0) {
+        d->value |= dec_read_byte(d) << d->bits_needed;
+        d->bits_needed -= 8;
+      }
+    }
+    return bins;
+  }
+  unsigned rem = n;
+  while (rem > 8) {
+    d->value = (d->value << 8) + (dec_read_byte(d) << (8 + d->bits_needed));
+    unsigned sr = d->range << 15;
+    for (int i = 0; i < 8; i++) {
+      bins += bins;
+      sr >>= 1;
+      if (d->value >= sr) {
+        bins++;
+        d->value -= sr;
+      }
+    }
+    rem -= 8;
+  }
+  d->bits_needed += (int)rem;
+  d->value <<= rem;
+  if (d->bits_needed >= 0) {
+    d->value += dec_read_byte(d) << d->bits_needed;
+    d->bits_needed -= 8;
+  }
+  unsigned sr = d->range << (rem + 7);
+  for (unsigned i = 0; i < rem; i++) {
+    bins += bins;
+    sr >>= 1;
+    if (d->value >= sr) {
+      bins++;
+      d->value -= sr;
+    }
+  }
+  return bins;
+}
+
+/* decodeRemAbsEP, arith_codec.cpp:153-179 */
+static unsigned dec_rem_abs(bin_dec *d, unsigned rice, unsigned cutoff, int max_log2) {
+  unsigned prefix = 0;
+  {
+    const unsigned max_prefix = 32 - (unsigned)max_log2;
+    unsigned cw;
+    do {
+      prefix++;
+      cw = dec_ep(d);
+    } while (cw && prefix < max_prefix);
+    prefix -= 1 - cw;
+  }
+  unsigned length = rice, offset;
+  if (prefix < cutoff) {
+    offset = prefix << rice;
+  } else {
+    offset = ((1u << (prefix - cutoff)) + cutoff - 1) << rice;
+    length += (prefix == (32u - (unsigned)max_log2)) ? (unsigned)max_log2 - rice : prefix - cutoff;
+  }
+  return offset + dec_bins_ep(d, length);
+}
+
+/* decodeBinTrm, arith_codec.cpp:181-197 */
+static unsigned dec_trm(bin_dec *d) {
+  d->range -= 2;
+  unsigned sr = d->range << 7;
+  if (d->value >= sr) return 1;
+  if (d->range < 256) {
+    d->range += d->range;
+    d->value += d->value;
+    if (++d->bits_needed == 0) {
+      d->value += dec_read_byte(d);
+      d->bits_needed = -8;
+    }
+  }
+  return 0;
+}
+
+/* BinDecoderBase::finish, arith_codec.cpp:68-73 (+ peekPreviousByte, bit_stream.cpp:276-279) */
+static int dec_finish(const bin_dec *d) {
+  if (d->idx == 0 || d->idx > d->n_in) return -5;
+  unsigned last = d->in[d->idx - 1];
+  if (((last << (8 + d->bits_needed)) & 0xff) != 0x80) return -5;
+  return 0;
+}
+
+int orc_decode_records(const uint16_t *rec, long n, int qp, int init_id, int flags,
+                       const uint8_t *in, long n_in, uint8_t *bins, uint32_t *n_bits_read) {
+  bin_dec d;
+  memset(&d, 0, sizeof d);
+  d.in = in;
+  d.n_in = n_in;
+  ctx_store_init(&d.ctx, qp, init_id);
+  dec_start(&d);
+  for (long i = 0; i < n; i++) {
+    unsigned id = rec[i] & CABAC_REC_ID_MASK;
+    if (id < ORC_NUM_CTX) bins[i] = (uint8_t)dec_bin(&d, id);
+    else if (id == CABAC_REC_EP) bins[i] = (uint8_t)dec_ep(&d);
+    else if (id == CABAC_REC_TRM) bins[i] = (uint8_t)dec_trm(&d);
+    else if (id == CABAC_REC_ALIGN) { d.range = 256; bins[i] = 0; }
+    else return -2;
+    if (d.underrun) return -4;
+  }
+  if (n_bits_read) *n_bits_read = (uint32_t)(8 * d.idx + d.bits_needed);
+  if (d.underrun) return -4;
+  if (flags & 1) return dec_finish(&d);
+  return 0;
+}
+
+/* reader-side binarisation twins: cabac_reader.cpp:3349-3379, :1162-1186 */
+static unsigned bz_read_unary_max(bin_dec *d, unsigned c0, unsigned cn, unsigned mx) {
+  unsigned ones = 0;
+  while (ones < mx && dec_bin(d, ones == 0 ? c0 : cn) == 1) ++ones;
+  return ones;
+}
+static unsigned bz_read_unary_ep(bin_dec *d, unsigned mx) {
+  for (unsigned k = 0; k < mx; k++)
+    if (!dec_ep(d)) return k;
+  return mx;
+}
+static unsigned bz_read_exp_golomb(bin_dec *d, unsigned count) {
+  unsigned symbol = 0, bit = 1;
+  while (bit) {
+    bit = dec_ep(d);
+    symbol += bit << count++;
+  }
+  if (--count) symbol += dec_bins_ep(d, count);
+  return symbol;
+}
+static unsigned bz_read_trunc_bin(bin_dec *d, unsigned mx) {
+  unsigned thresh = floor_log2(mx), val = 1u << thresh, b = mx - val;
+  unsigned symbol = dec_bins_ep(d, thresh);
+  if (symbol >= val - b) {
+    unsigned alt = dec_ep(d);
+    symbol = (symbol << 1) + alt - (val - b);
+  }
+  return symbol;
+}
+
+int orc_decode_ops(const uint32_t *ops, long n_ops, int qp, int init_id, int flags,
+                   const uint8_t *in, long n_in, uint32_t *values) {
+  bin_dec d;
+  memset(&d, 0, sizeof d);
+  d.in = in;
+  d.n_in = n_in;
+  ctx_store_init(&d.ctx, qp, init_id);
+  dec_start(&d);
+  for (long i = 0; i < n_ops; i++) {
+    const uint32_t *o = ops + 4 * i;
+    uint32_t v = 0;
+    switch (o[0]) {
+    case ORC_OP_ENC_BIN:
+      if (o[2] >= ORC_NUM_CTX) return -2;
+      v = dec_bin(&d, o[2]);
+      break;
+    case ORC_OP_ENC_EP: v = dec_ep(&d); break;
+    case ORC_OP_ENC_BINS_EP: v = dec_bins_ep(&d, o[2]); break;
+    case ORC_OP_ENC_REM_ABS: v = dec_rem_abs(&d, o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+    case ORC_OP_ENC_TRM: v = dec_trm(&d); break;
+    case ORC_OP_ALIGN: d.range = 256; break;
+    case ORC_OP_UNARY_MAX: v = bz_read_unary_max(&d, o[2] & 0xffff, o[2] >> 16, o[3]); break;
+    case ORC_OP_UNARY_EP: v = bz_read_unary_ep(&d, o[2]); break;
+    case ORC_OP_EXP_GOLOMB: v = bz_read_exp_golomb(&d, o[2]); break;
+    case ORC_OP_TRUNC_BIN: v = bz_read_trunc_bin(&d, o[2]); break;
+    default: return -2;
+    }
+    values[i] = v;
+    if (d.underrun) return -4;
+  }
+  if (flags & 1) return dec_finish(&d);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- batch helpers */
+void orc_encode_batch(const void *desc_, uint32_t first, uint32_t count, const uint16_t *records,
+                      uint8_t *bytes, uint32_t *results) {
+  const cabac_substream_desc *desc = (const cabac_substream_desc *)desc_;
+  for (uint32_t s = first; s < first + count; s++) {
+    const cabac_substream_desc *d = &desc[s];
+    int flags = ((d->init_id & CABAC_SUB_FINISH) ? 1 : 0) | ((d->init_id & CABAC_SUB_ALIGN_RBSP) ? 2 : 0);
+    uint32_t nbits = 0;
+    long rc = orc_encode_records(records + d->rec_offset, d->n_records, d->qp, (int)(d->init_id & 3),
+                                 flags, bytes + d->byte_offset, d->byte_capacity, &nbits);
+    results[2 * s] = nbits;
+    results[2 * s + 1] = rc == -3 ? CABAC_RES_OVERFLOW : rc == -2 ? CABAC_RES_BAD_RECORD : 0;
+  }
+}
+
+void orc_decode_batch(const void *desc_, uint32_t first, uint32_t count, const uint16_t *records,
+                      const uint8_t *bytes, uint8_t *bins, uint32_t *results) {
+  const cabac_substream_desc *desc = (const cabac_substream_desc *)desc_;
+  for (uint32_t s = first; s < first + count; s++) {
+    const cabac_substream_desc *d = &desc[s];
+    uint32_t nbits = 0;
+    int rc = orc_decode_records(records + d->rec_offset, d->n_records, d->qp, (int)(d->init_id & 3),
+                                (d->init_id & CABAC_SUB_FINISH) ? 1 : 0, bytes + d->byte_offset,
+                                d->byte_capacity, bins + d->rec_offset, &nbits);
+    results[2 * s] = nbits;
+    results[2 * s + 1] = rc == -4   ? CABAC_RES_UNDERRUN
+                         : rc == -5 ? CABAC_RES_BAD_STOP
+                         : rc == -2 ? CABAC_RES_BAD_RECORD
+                                    : 0;
+  }
+}

@@ -1,0 +1,73 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the reference's CABAC bin codec, used ONLY as the parity
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+ * library (libcabac_hip.so) never includes, links or loads anything from oracle/.
+ *
+ * Parity status: PINNED — checked bit-exact against the reference's own compiled sources
+ * (oracle/_ref/libcabac_ref.so, built by oracle/Makefile) by tests/test_oracle_vs_reference.py
+ * in the build container, and against the golden vectors under tests/golden/ (generated from
+ * that compiled reference by oracle/gen_golden.py) everywhere else.
+ */
+#ifndef CABAC_ORACLE_H
+#define CABAC_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Operation stream — identical codes to oracle/ref_harness.cpp.  One op = 4 x uint32. */
+enum {
+  ORC_OP_ENC_BIN = 0,     /* a = bin, b = ctxId                                  */
+  ORC_OP_ENC_EP = 1,      /* a = bin                                             */
+  ORC_OP_ENC_BINS_EP = 2, /* a = bins, b = numBins                               */
+  ORC_OP_ENC_REM_ABS = 3, /* a = value, b = rice, c = cutoff | maxLog2TrDR << 8  */
+  ORC_OP_ENC_TRM = 4,     /* a = bin                                             */
+  ORC_OP_ALIGN = 5,
+  ORC_OP_UNARY_MAX = 6,  /* a = symbol, b = ctxId0 | ctxIdN << 16, c = maxSymbol */
+  ORC_OP_UNARY_EP = 7,   /* a = symbol, b = maxSymbol                            */
+  ORC_OP_EXP_GOLOMB = 8, /* a = symbol, b = count                                */
+  ORC_OP_TRUNC_BIN = 9   /* a = symbol, b = maxSymbol                            */
+};
+
+#define ORC_NUM_CTX 379
+
+/* Ctx::init(qp, initId): reference contexts.cpp:893-901, :915-920, :996-1015 */
+void orc_ctx_init(int qp, int init_id, uint16_t *s0, uint16_t *s1, uint8_t *rate);
+
+/* One context traced through n updates (contexts.cpp:903-913, :939-950). */
+void orc_ctx_trace(int qp, int init_id, int ctx_id, const uint8_t *bins, int n, unsigned range,
+                   uint8_t *state8, uint8_t *lps, uint16_t *s0_after, uint16_t *s1_after);
+
+/* flags: bit0 finish(), bit1 writeByteAlignment().  Returns bytes written to out (whole bytes
+ * plus one MSB-aligned partial byte if *n_bits % 8), or <0: -2 bad op/record, -3 capacity.
+ * n_bins_out (may be NULL): {ctx, EP, TRM} BinCounter totals (arith_codec.cpp:281-316). */
+long orc_encode_ops(const uint32_t *ops, long n_ops, int qp, int init_id, int flags, uint8_t *out,
+                    long cap, uint32_t *n_bits, uint32_t *n_bins_out);
+long orc_encode_records(const uint16_t *rec, long n, int qp, int init_id, int flags, uint8_t *out,
+                        long cap, uint32_t *n_bits);
+
+/* Returns 0; -2 bad record; -4 read past end of input (reference: "FIFO exceeded");
+ * -5 stop pattern check of finish() failed.  flags bit0: run finish(). */
+int orc_decode_records(const uint16_t *rec, long n, int qp, int init_id, int flags,
+                       const uint8_t *in, long n_in, uint8_t *bins, uint32_t *n_bits_read);
+int orc_decode_ops(const uint32_t *ops, long n_ops, int qp, int init_id, int flags,
+                   const uint8_t *in, long n_in, uint32_t *values);
+
+/* Binarisation: expand an op stream into bin records (include/cabac_hip.h format).
+ * Returns the number of records (call with rec == NULL to size), or -2 on a bad op. */
+long orc_ops_to_records(const uint32_t *ops, long n_ops, uint16_t *rec, long cap);
+
+/* Batch helpers over substream descriptors laid out like cabac_substream_desc
+ * (include/cabac_hip.h) — used by the parity tests and the CPU baseline. `results`
+ * is an array of {n_bits, flags} pairs.  Substreams [first, first+count) are coded. */
+void orc_encode_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
+                      uint8_t *bytes, uint32_t *results);
+void orc_decode_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
+                      const uint8_t *bytes, uint8_t *bins, uint32_t *results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

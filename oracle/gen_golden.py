@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates tests/golden/*.npz + synth_md5.json from the reference's OWN
+compiled sources (oracle/_ref/libcabac_ref.so; see oracle/Makefile and oracle/ref_harness.cpp).
+Run in the build container only — /root/reference does not exist on the GPU box.  The fixtures
+are data (inputs + expected outputs); no reference source text is stored.
+
+    make -C oracle && python oracle/gen_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import helpers as H  # noqa: E402
+from entropy_coding_amd import capi  # noqa: E402  (only cabac_synth_records: the workload generator)
+from entropy_coding_amd.workload import CONFIGS  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    ref = H.load_ref()
+    rng = np.random.default_rng(20261004)
+    out = {}
+
+    # (a) Ctx::init dumps
+    qps, ids = [0, 17, 32, 51, 63, -5, 70], [0, 1, 2]
+    init = np.zeros((len(qps), len(ids), 3, 379), np.uint16)
+    for i, qp in enumerate(qps):
+        for j, iid in enumerate(ids):
+            s0, s1, rate = ref.ctx_init(qp, iid)
+            init[i, j, 0], init[i, j, 1], init[i, j, 2] = s0, s1, rate
+    out["ctx_init_qps"] = np.array(qps, np.int32)
+    out["ctx_init"] = init
+
+    # (b) per-context state traces
+    tr_meta, tr_bins, tr_out = [], [], []
+    for t in range(16):
+        qp, iid, ctx = int(rng.integers(0, 64)), int(rng.integers(0, 3)), int(rng.integers(0, 379))
+        p = [0.0, 0.05, 0.5, 0.95, 1.0][t % 5]
+        bins = (rng.random(256) < p).astype(np.uint8)
+        rg = int(rng.integers(256, 511))
+        st, lps, a, b = ref.ctx_trace(qp, iid, ctx, bins, rg)
+        tr_meta.append([qp, iid, ctx, rg])
+        tr_bins.append(bins)
+        tr_out.append(np.stack([st.astype(np.uint16), lps.astype(np.uint16), a, b]))
+    out["trace_meta"] = np.array(tr_meta, np.int32)
+    out["trace_bins"] = np.stack(tr_bins)
+    out["trace_out"] = np.stack(tr_out)
+
+    # (c)+(d) op streams covering every entry point -> bytes; decoded symbols
+    cases = []
+    for t in range(12):
+        n = [0, 1, 5, 64, 65, 500, 2000, 2000, 3000, 3000, 4000, 6000][t]
+        ops = H.random_ops(rng, n, ctx_frac=[0.0, 0.3, 0.6, 0.9][t % 4], with_align=(t % 5 == 4))
+        qp, iid = int(rng.integers(0, 64)), int(rng.integers(0, 3))
+        b3, nbits3, nbins = ref.encode_ops(ops, qp, iid, 3)
+        b1, nbits1, _ = ref.encode_ops(ops, qp, iid, 1)
+        rc, vals = ref.decode_ops(ops, qp, iid, b3, 1)
+        assert rc == 0
+        cases.append((ops, qp, iid, b3, nbits3, b1, nbits1, nbins, vals))
+    # long outstanding-0xFF runs + carry resolution (arith_codec.cpp:524-546)
+    for t in range(4):
+        n = int(rng.integers(100, 600))
+        ops = np.zeros((n + 3, 4), np.uint32)
+        ops[:n] = (H.OP_EP, 1, 0, 0)
+        ops[n] = (H.OP_BIN, t & 1, int(rng.integers(0, 379)), 0)
+        ops[n + 1] = (H.OP_BINS_EP, int(rng.integers(0, 1 << 16)), 16, 0)
+        ops[n + 2] = (H.OP_TRM, 1, 0, 0)
+        b3, nbits3, nbins = ref.encode_ops(ops, 30, 2, 3)
+        b1, nbits1, _ = ref.encode_ops(ops, 30, 2, 1)
+        rc, vals = ref.decode_ops(ops, 30, 2, b3, 1)
+        assert rc == 0
+        cases.append((ops, 30, 2, b3, nbits3, b1, nbits1, nbins, vals))
+    out["n_cases"] = np.array([len(cases)], np.int32)
+    for k, (ops, qp, iid, b3, nbits3, b1, nbits1, nbins, vals) in enumerate(cases):
+        out["case%d_ops" % k] = ops
+        out["case%d_meta" % k] = np.array([qp, iid, nbits3, nbits1], np.int64)
+        out["case%d_bytes_aligned" % k] = b3
+        out["case%d_bytes_finish" % k] = b1
+        out["case%d_nbins" % k] = nbins
+        out["case%d_values" % k] = vals
+    np.savez_compressed(os.path.join(GOLD, "vectors.npz"), **out)
+
+    # (e) synthetic workloads C1..C5: md5 of the reference's bytes per substream
+    synth = {}
+    for name, cfg in CONFIGS.items():
+        subs = cfg.golden_substreams()
+        per = []
+        cat = hashlib.md5()
+        for idx in subs:
+            n, permille, qp = cfg.substream(idx)
+            rec = capi.synth_records(cfg.seed, idx, n, permille)
+            b, nbits = ref.encode_records(rec, qp, 2, 3)
+            rc, bins, _ = ref.decode_records(rec, qp, 2, b, 1)
+            assert rc == 0 and np.array_equal(bins, (rec >> 15).astype(np.uint8))
+            per.append({"index": int(idx), "n_records": int(n), "n_bits": int(nbits),
+                        "md5": hashlib.md5(b.tobytes()).hexdigest(),
+                        "records_md5": hashlib.md5(rec.tobytes()).hexdigest()})
+            cat.update(b.tobytes())
+        synth[name] = {"seed": cfg.seed, "substreams": per, "concat_md5": cat.hexdigest()}
+    with open(os.path.join(GOLD, "synth_md5.json"), "w") as f:
+        json.dump(synth, f, indent=1)
+    print("wrote", os.path.join(GOLD, "vectors.npz"), os.path.getsize(os.path.join(GOLD, "vectors.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,294 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// C-callable driver around the *reference's own* classes, compiled together with
+// the reference sources where they lie under /root/reference (see oracle/Makefile,
+// target _ref/libcabac_ref.so).  Nothing from the reference is copied into this
+// repository: this file only #includes its headers at build time.
+//
+// It is used (a) to validate oracle/cabac_oracle.c, (b) to generate the golden
+// vectors under tests/golden/ (oracle/gen_golden.py) and (c) optionally as the
+// "reference" CPU baseline of bench.py.  Product code never links or loads it.
+//
+// Private binarisation helpers of CABACWriter/CABACReader (cabac_writer.hpp:165-174,
+// cabac_reader.hpp:125-132) are reached with the usual access-macro trick, in this
+// translation unit only; the reference objects are compiled unmodified.
+// every standard header the reference pulls in is included first, so that the access
+// macros below only ever apply to the reference's own class definitions
+#include <algorithm>
+#include <array>
+#include <bitset>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <exception>
+#include <fstream>
+#include <functional>
+#include <initializer_list>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <set>
+#include <sstream>
+#include <stack>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#define private public
+#define protected public
+#include "cabac_reader.hpp"
+#include "cabac_writer.hpp"
+#undef private
+#undef protected
+#include "arith_codec.hpp"
+#include "bit_stream.hpp"
+#include "contexts.hpp"
+
+using namespace EntropyCoding;
+using namespace Common;
+
+// Operation stream shared by ref_harness.cpp, cabac_oracle.c and the host shim tests.
+// One op = 4 x uint32 {code, a, b, c}.
+enum {
+  OP_ENC_BIN = 0,      // a = bin, b = ctxId
+  OP_ENC_EP = 1,       // a = bin
+  OP_ENC_BINS_EP = 2,  // a = bins, b = numBins
+  OP_ENC_REM_ABS = 3,  // a = value, b = rice, c = cutoff | maxLog2TrDR << 8
+  OP_ENC_TRM = 4,      // a = bin
+  OP_ALIGN = 5,
+  OP_UNARY_MAX = 6,   // a = symbol, b = ctxId0 | ctxIdN << 16, c = maxSymbol
+  OP_UNARY_EP = 7,    // a = symbol, b = maxSymbol
+  OP_EXP_GOLOMB = 8,  // a = symbol, b = count
+  OP_TRUNC_BIN = 9,   // a = symbol, b = maxSymbol
+};
+
+static thread_local char g_err[512];
+
+extern "C" {
+
+const char *ref_last_error() { return g_err; }
+
+int ref_num_contexts() { return (int)Ctx::NumberOfContexts; }
+
+int ref_sizeof_prob_model() { return (int)sizeof(BinProbModel_Std); }
+
+// row 0..2 = B,P,I slice init values, row 3 = window sizes (contexts.cpp:73-74)
+int ref_init_table(int row, uint8_t *out) {
+  try {
+    const std::vector<uint8_t> &t = ContextSetCfg::getInitTable((unsigned)row);
+    memcpy(out, t.data(), t.size());
+    return (int)t.size();
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Ctx::init(qp, initId) -> per-context (state0, state1, rate)
+int ref_ctx_init(int qp, int initId, uint16_t *s0, uint16_t *s1, uint8_t *rate) {
+  try {
+    BinEncoder_Std enc;
+    static_cast<BinEncIf &>(enc).getCtx().init(qp, initId);
+    CtxStore<BinProbModel_Std> &st =
+        static_cast<CtxStore<BinProbModel_Std> &>(static_cast<BinEncIf &>(enc).getCtx());
+    for (unsigned k = 0; k < Ctx::NumberOfContexts; k++) {
+      s0[k] = st[k].getState0();
+      s1[k] = st[k].getState1();
+      rate[k] = st[k].getRate();
+    }
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Scripted update of one context: init (qp, initId), then update(bin) for each bin;
+// records state()/mps()/getLPS(range) *before* each update and the states after.
+int ref_ctx_trace(int qp, int initId, int ctxId, const uint8_t *bins, int n, unsigned range,
+                  uint8_t *state8, uint8_t *lps, uint16_t *s0_after, uint16_t *s1_after) {
+  try {
+    BinEncoder_Std enc;
+    static_cast<BinEncIf &>(enc).getCtx().init(qp, initId);
+    CtxStore<BinProbModel_Std> &st =
+        static_cast<CtxStore<BinProbModel_Std> &>(static_cast<BinEncIf &>(enc).getCtx());
+    BinProbModel_Std &m = st[ctxId];
+    for (int i = 0; i < n; i++) {
+      state8[i] = m.state();
+      lps[i] = m.getLPS(range);
+      m.update(bins[i]);
+      s0_after[i] = m.getState0();
+      s1_after[i] = m.getState1();
+    }
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Run an op stream through BinEncoder_Std (+ CABACWriter helpers).
+//   flags bit0: call finish() at the end; bit1: then writeByteAlignment()
+// out receives m_fifo followed (if any held bits) by the held byte; *n_bits =
+// getNumberOfWrittenBits(); n_bins_out[0..2] = ctx/EP/TRM BinCounter totals.
+long ref_encode_ops(const uint32_t *ops, long n_ops, int qp, int initId, int flags, uint8_t *out,
+                    long cap, uint32_t *n_bits, uint32_t *n_bins_out) {
+  try {
+    BinEncoder_Std enc;
+    OutputBitstream bs;
+    CABACWriter w(enc);
+    w.initBitstream(&bs);
+    enc.reset(qp, initId);
+    BinEncIf &e = enc;
+    for (long i = 0; i < n_ops; i++) {
+      const uint32_t *o = ops + 4 * i;
+      switch (o[0]) {
+      case OP_ENC_BIN: e.encodeBin(o[1], o[2]); break;
+      case OP_ENC_EP: e.encodeBinEP(o[1]); break;
+      case OP_ENC_BINS_EP: e.encodeBinsEP(o[1], o[2]); break;
+      case OP_ENC_REM_ABS: e.encodeRemAbsEP(o[1], o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+      case OP_ENC_TRM: e.encodeBinTrm(o[1]); break;
+      case OP_ALIGN: e.align(); break;
+      case OP_UNARY_MAX: w.unary_max_symbol(o[1], o[2] & 0xffff, o[2] >> 16, o[3]); break;
+      case OP_UNARY_EP: w.unary_max_eqprob(o[1], o[2]); break;
+      case OP_EXP_GOLOMB: w.exp_golomb_eqprob(o[1], o[2]); break;
+      case OP_TRUNC_BIN: w.xWriteTruncBinCode(o[1], o[2]); break;
+      default: strcpy(g_err, "bad op"); return -2;
+      }
+    }
+    if (n_bins_out) {
+      uint32_t nctx = 0;
+      for (unsigned k = 0; k < Ctx::NumberOfContexts; k++) nctx += e.getNumBins(k);
+      n_bins_out[0] = nctx;
+      n_bins_out[1] = enc.getEP();
+      n_bins_out[2] = enc.getTrm();
+    }
+    if (flags & 1) e.finish();
+    if (flags & 2) bs.writeByteAlignment();
+    *n_bits = bs.getNumberOfWrittenBits();
+    const std::vector<uint8_t> &f = bs.getFIFO();
+    long n = (long)f.size();
+    long total = n + ((*n_bits & 7) ? 1 : 0);
+    if (total > cap) { strcpy(g_err, "capacity"); return -3; }
+    if (n) memcpy(out, f.data(), n);
+    if (*n_bits & 7) out[n] = bs.getHeldBits();
+    return total;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Bin-record stream (include/cabac_hip.h) through BinEncoder_Std.
+long ref_encode_records(const uint16_t *rec, long n, int qp, int initId, int flags, uint8_t *out,
+                        long cap, uint32_t *n_bits) {
+  try {
+    BinEncoder_Std enc;
+    OutputBitstream bs;
+    enc.init(&bs);
+    enc.reset(qp, initId);
+    BinEncIf &e = enc;
+    for (long i = 0; i < n; i++) {
+      unsigned id = rec[i] & 0x1ff, bin = rec[i] >> 15;
+      if (id < Ctx::NumberOfContexts) e.encodeBin(bin, id);
+      else if (id == 0x1fe) e.encodeBinEP(bin);
+      else if (id == 0x1ff) e.encodeBinTrm(bin);
+      else if (id == 0x1fd) e.align();
+      else { strcpy(g_err, "bad record"); return -2; }
+    }
+    if (flags & 1) e.finish();
+    if (flags & 2) bs.writeByteAlignment();
+    *n_bits = bs.getNumberOfWrittenBits();
+    const std::vector<uint8_t> &f = bs.getFIFO();
+    long nb = (long)f.size();
+    long total = nb + ((*n_bits & 7) ? 1 : 0);
+    if (total > cap) { strcpy(g_err, "capacity"); return -3; }
+    if (nb) memcpy(out, f.data(), nb);
+    if (*n_bits & 7) out[nb] = bs.getHeldBits();
+    return total;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Bin-record stream through BinDecoder_Std.  flags bit0: call finish() at the end.
+// Returns 0, or -1 with ref_last_error() on a reference exception (e.g. FIFO exceeded,
+// missing stop pattern).  *n_bits_read = 8*m_fifo_idx + bitsNeeded.
+int ref_decode_records(const uint16_t *rec, long n, int qp, int initId, int flags,
+                       const uint8_t *in, long n_in, uint8_t *bins, uint32_t *n_bits_read) {
+  try {
+    BinDecoder_Std dec;
+    InputBitstream ib;
+    ib.getFifo().assign(in, in + n_in);
+    dec.init(&ib);
+    dec.reset(qp, initId);
+    for (long i = 0; i < n; i++) {
+      unsigned id = rec[i] & 0x1ff;
+      if (id < Ctx::NumberOfContexts) bins[i] = (uint8_t)dec.decodeBin(id);
+      else if (id == 0x1fe) bins[i] = (uint8_t)dec.decodeBinEP();
+      else if (id == 0x1ff) bins[i] = (uint8_t)dec.decodeBinTrm();
+      else if (id == 0x1fd) { dec.align(); bins[i] = 0; }
+      else { strcpy(g_err, "bad record"); return -2; }
+    }
+    if (n_bits_read) *n_bits_read = 8u * ib.getByteLocation() + (uint32_t)dec.m_bitsNeeded;
+    if (flags & 1) dec.finish();
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// Decode-side op stream: values[i] receives the decoded symbol of op i.
+//   OP_ENC_BIN -> decodeBin(b)         OP_ENC_EP -> decodeBinEP()
+//   OP_ENC_BINS_EP -> decodeBinsEP(b)  OP_ENC_REM_ABS -> decodeRemAbsEP(b, c&0xff, c>>8)
+//   OP_ENC_TRM -> decodeBinTrm()       OP_UNARY_MAX/UNARY_EP/EXP_GOLOMB/TRUNC_BIN -> reader twins
+int ref_decode_ops(const uint32_t *ops, long n_ops, int qp, int initId, int flags,
+                   const uint8_t *in, long n_in, uint32_t *values) {
+  try {
+    BinDecoder_Std dec;
+    InputBitstream ib;
+    ib.getFifo().assign(in, in + n_in);
+    CABACReader r(dec);
+    r.initBitstream(&ib);
+    dec.reset(qp, initId);
+    for (long i = 0; i < n_ops; i++) {
+      const uint32_t *o = ops + 4 * i;
+      uint32_t v = 0;
+      switch (o[0]) {
+      case OP_ENC_BIN: v = dec.decodeBin(o[2]); break;
+      case OP_ENC_EP: v = dec.decodeBinEP(); break;
+      case OP_ENC_BINS_EP: v = dec.decodeBinsEP(o[2]); break;
+      case OP_ENC_REM_ABS: v = dec.decodeRemAbsEP(o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+      case OP_ENC_TRM: v = dec.decodeBinTrm(); break;
+      case OP_ALIGN: dec.align(); break;
+      case OP_UNARY_MAX: v = r.unary_max_symbol(o[2] & 0xffff, o[2] >> 16, o[3]); break;
+      case OP_UNARY_EP: v = r.unary_max_eqprob(o[2]); break;
+      case OP_EXP_GOLOMB: v = r.exp_golomb_eqprob(o[2]); break;
+      case OP_TRUNC_BIN: r.xReadTruncBinCode(v, o[2]); break;
+      default: strcpy(g_err, "bad op"); return -2;
+      }
+      values[i] = v;
+    }
+    if (flags & 1) dec.finish();
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+} // extern "C"

@@ -1,0 +1,297 @@
+"""Shared test plumbing: ctypes loaders for the oracle (oracle/libcabac_oracle.so), the compiled
+reference (oracle/_ref/libcabac_ref.so, build container only) and random op/record generators.
+
+The oracle and the reference harness are TEST INFRASTRUCTURE; product code never loads them."""
+import ctypes
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+NUM_CTX = 379
+REC_BIN = 0x8000
+REC_ALIGN, REC_EP, REC_TRM = 0x1FD, 0x1FE, 0x1FF
+SUB_FINISH, SUB_ALIGN_RBSP = 0x100, 0x200
+
+OP_BIN, OP_EP, OP_BINS_EP, OP_REM_ABS, OP_TRM, OP_ALIGN = 0, 1, 2, 3, 4, 5
+OP_UNARY_MAX, OP_UNARY_EP, OP_EXP_GOLOMB, OP_TRUNC_BIN = 6, 7, 8, 9
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+
+DESC_DTYPE = np.dtype(
+    [
+        ("rec_offset", "<u8"),
+        ("byte_offset", "<u8"),
+        ("n_records", "<u4"),
+        ("byte_capacity", "<u4"),
+        ("qp", "<i4"),
+        ("init_id", "<u4"),
+    ]
+)
+RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+class CodecLib:
+    """Uniform wrapper over the `orc_*` (oracle) or `ref_*` (compiled reference) entry points."""
+
+    def __init__(self, lib, prefix):
+        self.lib = lib
+        self.p = prefix
+        L = lib
+        g = lambda n: getattr(L, prefix + n)
+        g("encode_ops").restype = ctypes.c_long
+        g("encode_ops").argtypes = [u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p,
+                                    ctypes.c_long, u32p, u32p]
+        g("encode_records").restype = ctypes.c_long
+        g("encode_records").argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p,
+                                        ctypes.c_long, u32p]
+        g("decode_records").restype = ctypes.c_int
+        g("decode_records").argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p,
+                                        ctypes.c_long, u8p, u32p]
+        g("decode_ops").restype = ctypes.c_int
+        g("decode_ops").argtypes = [u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p,
+                                    ctypes.c_long, u32p]
+        g("ctx_init").argtypes = [ctypes.c_int, ctypes.c_int, u16p, u16p, u8p]
+        g("ctx_trace").argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int, ctypes.c_uint,
+                                   u8p, u8p, u16p, u16p]
+        if prefix == "orc_":
+            L.orc_ops_to_records.restype = ctypes.c_long
+            L.orc_ops_to_records.argtypes = [u32p, ctypes.c_long, u16p, ctypes.c_long]
+            L.orc_encode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u16p, u8p, u32p]
+            L.orc_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u16p, u8p, u8p, u32p]
+
+    # -- encode ---------------------------------------------------------------
+    def encode_ops(self, ops, qp, init_id, flags=1):
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 4)
+        cap = 64 + 8 * len(ops) * 5
+        out = np.zeros(cap, np.uint8)
+        nbits = ctypes.c_uint32(0)
+        nbins = np.zeros(3, np.uint32)
+        n = getattr(self.lib, self.p + "encode_ops")(_ptr(ops, u32p), len(ops), qp, init_id, flags,
+                                                     _ptr(out, u8p), cap, ctypes.byref(nbits), _ptr(nbins, u32p))
+        if n < 0:
+            raise RuntimeError("%sencode_ops failed: %d" % (self.p, n))
+        return out[:n].copy(), nbits.value, nbins
+
+    def encode_records(self, rec, qp, init_id, flags=1):
+        rec = np.ascontiguousarray(rec, dtype=np.uint16)
+        cap = 64 + len(rec)
+        out = np.zeros(cap, np.uint8)
+        nbits = ctypes.c_uint32(0)
+        n = getattr(self.lib, self.p + "encode_records")(_ptr(rec, u16p), len(rec), qp, init_id, flags,
+                                                         _ptr(out, u8p), cap, ctypes.byref(nbits))
+        if n < 0:
+            raise RuntimeError("%sencode_records failed: %d" % (self.p, n))
+        return out[:n].copy(), nbits.value
+
+    # -- decode ---------------------------------------------------------------
+    def decode_records(self, rec, qp, init_id, data, flags=0):
+        rec = np.ascontiguousarray(rec, dtype=np.uint16)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        bins = np.zeros(max(len(rec), 1), np.uint8)
+        nread = ctypes.c_uint32(0)
+        rc = getattr(self.lib, self.p + "decode_records")(_ptr(rec, u16p), len(rec), qp, init_id, flags,
+                                                          _ptr(data, u8p), len(data), _ptr(bins, u8p),
+                                                          ctypes.byref(nread))
+        return rc, bins[: len(rec)], nread.value
+
+    def decode_ops(self, ops, qp, init_id, data, flags=0):
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 4)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        vals = np.zeros(max(len(ops), 1), np.uint32)
+        rc = getattr(self.lib, self.p + "decode_ops")(_ptr(ops, u32p), len(ops), qp, init_id, flags,
+                                                      _ptr(data, u8p), len(data), _ptr(vals, u32p))
+        return rc, vals[: len(ops)]
+
+    # -- context model --------------------------------------------------------
+    def ctx_init(self, qp, init_id):
+        s0 = np.zeros(NUM_CTX, np.uint16)
+        s1 = np.zeros(NUM_CTX, np.uint16)
+        rate = np.zeros(NUM_CTX, np.uint8)
+        getattr(self.lib, self.p + "ctx_init")(qp, init_id, _ptr(s0, u16p), _ptr(s1, u16p), _ptr(rate, u8p))
+        return s0, s1, rate
+
+    def ctx_trace(self, qp, init_id, ctx_id, bins, rng):
+        bins = np.ascontiguousarray(bins, dtype=np.uint8)
+        n = len(bins)
+        st = np.zeros(n, np.uint8)
+        lps = np.zeros(n, np.uint8)
+        a = np.zeros(n, np.uint16)
+        b = np.zeros(n, np.uint16)
+        getattr(self.lib, self.p + "ctx_trace")(qp, init_id, ctx_id, _ptr(bins, u8p), n, rng, _ptr(st, u8p),
+                                                _ptr(lps, u8p), _ptr(a, u16p), _ptr(b, u16p))
+        return st, lps, a, b
+
+    # -- oracle only ----------------------------------------------------------
+    def ops_to_records(self, ops):
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 4)
+        n = self.lib.orc_ops_to_records(_ptr(ops, u32p), len(ops), None, 0)
+        if n < 0:
+            raise RuntimeError("ops_to_records failed")
+        rec = np.zeros(max(n, 1), np.uint16)
+        self.lib.orc_ops_to_records(_ptr(ops, u32p), len(ops), _ptr(rec, u16p), n)
+        return rec[:n]
+
+    def encode_batch(self, desc, records, bytes_total):
+        out = np.zeros(max(bytes_total, 1), np.uint8)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        self.lib.orc_encode_batch(desc.ctypes.data, 0, len(desc), _ptr(records, u16p), _ptr(out, u8p),
+                                  res.ctypes.data_as(u32p))
+        return out, res
+
+    def decode_batch(self, desc, records, data):
+        bins = np.zeros(max(len(records), 1), np.uint8)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        self.lib.orc_decode_batch(desc.ctypes.data, 0, len(desc), _ptr(records, u16p), _ptr(data, u8p),
+                                  _ptr(bins, u8p), res.ctypes.data_as(u32p))
+        return bins[: len(records)], res
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "libcabac_oracle.so")
+    src = os.path.join(ORACLE_DIR, "cabac_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libcabac_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_oracle = None
+_ref = None
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = CodecLib(ctypes.CDLL(build_oracle()), "orc_")
+    return _oracle
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libcabac_ref.so"))
+
+
+def load_ref():
+    """The reference's own sources compiled by oracle/Makefile (build container only)."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(ORACLE_DIR, "_ref", "libcabac_ref.so")
+        cwd = os.getcwd()
+        tmp = tempfile.mkdtemp(prefix="cabac_ref_")  # reference log.cpp:3-4 creates two files in CWD at load
+        os.chdir(tmp)
+        try:
+            lib = ctypes.CDLL(so)
+        finally:
+            os.chdir(cwd)
+        _ref = CodecLib(lib, "ref_")
+    return _ref
+
+
+# ------------------------------------------------------------------ generators
+def random_ops(rng, n, ctx_frac=0.6, p_one=None, with_helpers=True, with_align=False, end_trm=True):
+    """Random operation stream exercising every BinEncIf entry point and binarisation helper."""
+    ops = np.zeros((n + (1 if end_trm else 0), 4), np.uint32)
+    if p_one is None:
+        p_one = rng.choice([0.03, 0.1, 0.25, 0.5, 0.75, 0.9], size=NUM_CTX)
+    i = 0
+    while i < n:
+        r = rng.random()
+        if r < ctx_frac:
+            c = int(rng.integers(0, NUM_CTX))
+            ops[i] = (OP_BIN, int(rng.random() < p_one[c]), c, 0)
+        elif r < ctx_frac + 0.12:
+            ops[i] = (OP_EP, int(rng.integers(0, 2)), 0, 0)
+        elif r < ctx_frac + 0.20:
+            nb = int(rng.integers(0, 33))
+            v = int(rng.integers(0, 1 << 32)) & ((1 << nb) - 1) if nb else 0
+            ops[i] = (OP_BINS_EP, v, nb, 0)
+        elif r < ctx_frac + 0.30:
+            rice = int(rng.integers(0, 5))
+            mode = rng.random()
+            if mode < 0.7:
+                v = int(rng.integers(0, 64))
+            elif mode < 0.9:
+                v = int(rng.integers(0, 1 << 12))
+            else:
+                # long escapes incl. maxPrefixLength saturation (arith_codec.cpp:440-442); values stay
+                # inside the 15-bit transform dynamic range the callers guarantee — beyond it the
+                # reference's suffix no longer fits suffixLength bits and its own output is undefined
+                v = int(rng.integers(0, 1 << 15))
+            ops[i] = (OP_REM_ABS, v, rice, 5 | (15 << 8))
+        elif r < ctx_frac + 0.32:
+            ops[i] = (OP_TRM, 0, 0, 0)
+        elif with_align and r < ctx_frac + 0.33:
+            ops[i] = (OP_ALIGN, 0, 0, 0)
+        elif with_helpers:
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                mx = int(rng.integers(1, 12))
+                sym = int(rng.integers(0, mx + 1))
+                c0, cn = int(rng.integers(0, NUM_CTX)), int(rng.integers(0, NUM_CTX))
+                ops[i] = (OP_UNARY_MAX, sym, c0 | (cn << 16), mx)
+            elif k == 1:
+                mx = int(rng.integers(0, 32))
+                sym = int(rng.integers(0, mx + 1))
+                ops[i] = (OP_UNARY_EP, sym, mx, 0)
+            elif k == 2:
+                cnt = int(rng.integers(0, 4))
+                sym = int(rng.integers(0, 3000))
+                ops[i] = (OP_EXP_GOLOMB, sym, cnt, 0)
+            else:
+                mx = int(rng.integers(1, 700))
+                sym = int(rng.integers(0, mx))
+                ops[i] = (OP_TRUNC_BIN, sym, mx, 0)
+        else:
+            ops[i] = (OP_EP, int(rng.integers(0, 2)), 0, 0)
+        i += 1
+    if end_trm:
+        ops[n] = (OP_TRM, 1, 0, 0)
+    return ops
+
+
+def random_records(rng, n, ctx_frac=0.7, p_one=None, ctx_pool=None, end_trm=True, trm0_frac=0.002):
+    """Flat bin-record stream (include/cabac_hip.h)."""
+    if p_one is None:
+        p_one = rng.choice([0.03, 0.1, 0.25, 0.5, 0.75, 0.9], size=NUM_CTX)
+    if ctx_pool is None:
+        ctx_pool = np.arange(NUM_CTX)
+    r = rng.random(n)
+    ids = rng.choice(ctx_pool, size=n).astype(np.uint32)
+    bins = (rng.random(n) < np.asarray(p_one)[ids]).astype(np.uint32)
+    is_ep = r >= ctx_frac
+    is_trm = r >= 1.0 - trm0_frac
+    ids[is_ep] = REC_EP
+    bins[is_ep] = rng.integers(0, 2, size=int(is_ep.sum()))
+    ids[is_trm] = REC_TRM
+    bins[is_trm] = 0
+    rec = (ids | (bins << 15)).astype(np.uint16)
+    if end_trm:
+        rec = np.concatenate([rec, np.array([REC_TRM | REC_BIN], np.uint16)])
+    return rec
+
+
+def make_desc(lengths, qps, init_ids, flags=SUB_FINISH, capacities=None):
+    """Pack substreams back to back; capacity defaults to n/2 + 64 bytes (>= hard bound for the mixes used)."""
+    n = len(lengths)
+    d = np.zeros(n, DESC_DTYPE)
+    lengths = np.asarray(lengths, np.uint64)
+    d["n_records"] = lengths
+    d["rec_offset"] = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    if capacities is None:
+        capacities = (lengths * 3) // 4 + 64
+    capacities = (np.asarray(capacities, np.uint64) + 15) // 16 * 16
+    d["byte_capacity"] = capacities
+    d["byte_offset"] = np.concatenate([[0], np.cumsum(capacities)[:-1]])
+    d["qp"] = qps
+    d["init_id"] = np.asarray(init_ids, np.uint32) | flags
+    return d, int(capacities.sum())

@@ -1,0 +1,259 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of libcabac_hip.so) against the oracle on
+the same seeded inputs, against the committed golden vectors, and — at BASELINE.json's full sizes —
+through encode -> decode round trips.  Bit-exact everywhere (integer/byte work)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from entropy_coding_amd import capi
+from entropy_coding_amd.workload import CONFIGS, build_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    c = capi.CabacHip(0)   # raises without a GPU: there is no fallback
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(H.GOLDEN, "vectors.npz"))
+
+
+def _stream_bytes(out, desc, res, s):
+    nb = (int(res["n_bits"][s]) + 7) // 8
+    o = int(desc["byte_offset"][s])
+    return out[o:o + nb]
+
+
+def _compare_encode(hip, orc, desc, records, total):
+    out_g, res_g = hip.encode_batch(desc, records, total, check=False)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    assert np.array_equal(res_g["n_bits"], res_o["n_bits"])
+    assert np.array_equal(res_g["flags"], res_o["flags"])
+    for s in range(len(desc)):
+        if res_o["flags"][s] == 0:
+            assert np.array_equal(_stream_bytes(out_g, desc, res_g, s), _stream_bytes(out_o, desc, res_o, s)), s
+    return out_g, res_g
+
+
+def test_ctx_init_matches_oracle_and_golden(hip, gold):
+    import torch
+    orc = H.load_oracle()
+    qps = list(range(-2, 66)) * 3
+    ids = [0] * 68 + [1] * 68 + [2] * 68
+    n = len(qps)
+    d_qp = torch.tensor(qps, dtype=torch.int32, device="cuda")
+    d_id = torch.tensor(ids, dtype=torch.int32, device="cuda")
+    d_state = torch.zeros(n * 379, dtype=torch.int32, device="cuda")
+    d_rate = torch.zeros(n * 379, dtype=torch.uint8, device="cuda")
+    hip.ctx_init_device(n, d_qp.data_ptr(), d_id.data_ptr(), d_state.data_ptr(), d_rate.data_ptr())
+    hip.synchronize()
+    st = d_state.cpu().numpy().view(np.uint32).reshape(n, 379)
+    rt = d_rate.cpu().numpy().reshape(n, 379)
+    for k in range(n):
+        s0, s1, rate = orc.ctx_init(qps[k], ids[k])
+        assert np.array_equal(st[k] & 0xFFFF, s0) and np.array_equal(st[k] >> 16, s1) and np.array_equal(rt[k], rate)
+    for i, qp in enumerate(gold["ctx_init_qps"]):
+        for iid in range(3):
+            k = qps.index(max(-2, min(65, int(qp)))) + 68 * iid
+            g = gold["ctx_init"][i, iid]
+            assert np.array_equal(st[k] & 0xFFFF, g[0]) and np.array_equal(st[k] >> 16, g[1])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_encode_random_batches(hip, seed):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(300 + seed)
+    lens = [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096, 5000] + \
+        [int(x) for x in rng.integers(1, 3000, size=40)]
+    recs = [H.random_records(rng, max(n - 1, 0), ctx_frac=float(rng.choice([0.0, 0.5, 0.75, 1.0])),
+                             end_trm=(n > 0)) for n in lens]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs) if recs else np.zeros(0, np.uint16)
+    flags = [H.SUB_FINISH, H.SUB_FINISH | H.SUB_ALIGN_RBSP, 0][seed % 3]
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), rng.integers(0, 3, size=len(lens)), flags)
+    _compare_encode(hip, orc, desc, records, total)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_decode_random_batches(hip, seed):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(400 + seed)
+    lens = [1, 2, 63, 64, 65, 128, 129, 257, 1000, 5000] + [int(x) for x in rng.integers(1, 4000, size=30)]
+    recs = [H.random_records(rng, n - 1, ctx_frac=float(rng.choice([0.0, 0.5, 0.75, 1.0]))) for n in lens]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), rng.integers(0, 3, size=len(lens)),
+                              H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    data, res = orc.encode_batch(desc, records, total)
+    assert not res["flags"].any()
+    ddesc = desc.copy()
+    ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8          # exactly the valid bytes
+    bins_g, res_g = hip.decode_batch(ddesc, records, data)
+    bins_o, res_o = orc.decode_batch(ddesc, records, data)
+    assert np.array_equal(bins_g, bins_o) and np.array_equal(bins_g, (records >> 15).astype(np.uint8))
+    assert np.array_equal(res_g["n_bits"], res_o["n_bits"]) and not res_g["flags"].any()
+
+
+def test_golden_op_stream_cases(hip, gold):
+    """Reference-generated vectors: ops -> (oracle binariser) -> records -> HIP -> exact reference bytes."""
+    orc = H.load_oracle()
+    recs, metas = [], []
+    for k in range(int(gold["n_cases"][0])):
+        recs.append(orc.ops_to_records(gold["case%d_ops" % k]))
+        metas.append([int(x) for x in gold["case%d_meta" % k]])
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    for flags, key, col in ((H.SUB_FINISH | H.SUB_ALIGN_RBSP, "bytes_aligned", 2), (H.SUB_FINISH, "bytes_finish", 3)):
+        desc, total = H.make_desc(lens, [m[0] for m in metas], [m[1] for m in metas], flags)
+        out, res = hip.encode_batch(desc, records, total)
+        for k in range(len(recs)):
+            assert int(res["n_bits"][k]) == metas[k][col]
+            assert np.array_equal(_stream_bytes(out, desc, res, k), gold["case%d_%s" % (k, key)]), k
+    # decode the reference's bytes on the GPU
+    desc, total = H.make_desc(lens, [m[0] for m in metas], [m[1] for m in metas], H.SUB_FINISH,
+                              capacities=[len(gold["case%d_bytes_aligned" % k]) for k in range(len(recs))])
+    data = np.zeros(total, np.uint8)
+    for k in range(len(recs)):
+        b = gold["case%d_bytes_aligned" % k]
+        desc["byte_capacity"][k] = len(b)
+        data[int(desc["byte_offset"][k]):int(desc["byte_offset"][k]) + len(b)] = b
+    bins, res = hip.decode_batch(desc, records, data)
+    keep = (records & 0x1FF) != H.REC_ALIGN
+    assert np.array_equal(bins[keep], (records[keep] >> 15).astype(np.uint8)) and not res["flags"].any()
+
+
+def test_error_flags_match_oracle(hip):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(9)
+    rec_ok = H.random_records(rng, 3000)
+    rec_bad = rec_ok.copy()
+    rec_bad[100] = 400                      # id neither ctx nor special
+    records = np.concatenate([rec_ok, rec_bad, rec_ok])
+    lens = [len(rec_ok)] * 3
+    desc, total = H.make_desc(lens, [32] * 3, [2] * 3, H.SUB_FINISH | H.SUB_ALIGN_RBSP, capacities=[4096, 4096, 64])
+    out_g, res_g = hip.encode_batch(desc, records, total, check=False)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    assert list(res_g["flags"]) == [0, capi.RES_BAD_RECORD, capi.RES_OVERFLOW]
+    assert res_o["flags"][2] == capi.RES_OVERFLOW and np.array_equal(res_g["n_bits"][[0, 2]], res_o["n_bits"][[0, 2]])
+    with pytest.raises(capi.CabacHipError):
+        hip.encode_batch(desc, records, total, check=True)
+    # decode: truncated input -> UNDERRUN; zero-padded stream without stop bit -> BAD_STOP
+    d1, t1 = H.make_desc([len(rec_ok)], [32], [2], H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    data, res = orc.encode_batch(d1, rec_ok, t1)
+    nb = (int(res["n_bits"][0]) + 7) // 8
+    dd = d1.copy(); dd["byte_capacity"] = nb // 2
+    _, rg = hip.decode_batch(dd, rec_ok, data, check=False)
+    _, ro = orc.decode_batch(dd, rec_ok, data)
+    assert rg["flags"][0] & capi.RES_UNDERRUN and ro["flags"][0] & capi.RES_UNDERRUN
+    d2, _ = H.make_desc([len(rec_ok)], [32], [2], H.SUB_FINISH)
+    raw, res2 = orc.encode_batch(d2, rec_ok, t1)          # finish() without the stop bit
+    dd = d2.copy(); dd["byte_capacity"] = (int(res2["n_bits"][0]) + 7) // 8 + 4
+    _, rg = hip.decode_batch(dd, rec_ok, raw, check=False)
+    _, ro = orc.decode_batch(dd, rec_ok, raw)
+    assert rg["flags"][0] == ro["flags"][0]
+
+
+def test_ff_runs_and_carry(hip):
+    """writeOut's outstanding-0xFF counter and both finish() branches (arith_codec.cpp:524-546, :339-357)."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(77)
+    recs = []
+    for t in range(64):
+        n = int(rng.integers(50, 900))
+        head = np.full(n, H.REC_EP | H.REC_BIN, np.uint16)
+        tail = H.random_records(rng, int(rng.integers(1, 40)), ctx_frac=0.5)
+        recs.append(np.concatenate([head, tail]))
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, [30] * 64, [2] * 64, H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    out, res = _compare_encode(hip, orc, desc, records, total)
+    assert max(int((_stream_bytes(out, desc, res, s) == 0xFF).sum()) for s in range(64)) > 20
+    ddesc = desc.copy(); ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
+    bins, rd = hip.decode_batch(ddesc, records, out)
+    assert np.array_equal(bins, (records >> 15).astype(np.uint8)) and not rd["flags"].any()
+
+
+def test_single_context_worst_case(hip):
+    """Every bin on one context: the in-register state forwarding chain is 64 deep."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(5)
+    recs = []
+    for ctx in (0, 100, 378):
+        r = (np.full(5000, ctx, np.uint16) | ((rng.random(5000) < 0.3).astype(np.uint16) << 15))
+        recs.append(np.concatenate([r, np.array([H.REC_TRM | H.REC_BIN], np.uint16)]))
+    records = np.concatenate(recs)
+    desc, total = H.make_desc([len(r) for r in recs], [22, 32, 45], [2, 1, 0], H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    out, res = _compare_encode(hip, orc, desc, records, total)
+    ddesc = desc.copy(); ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
+    bins, rd = hip.decode_batch(ddesc, records, out)
+    assert np.array_equal(bins, (records >> 15).astype(np.uint8)) and not rd["flags"].any()
+
+
+def test_empty_batch(hip):
+    out, res = hip.encode_batch(np.zeros(0, capi.DESC_DTYPE), np.zeros(0, np.uint16), 0)
+    assert len(res) == 0
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+def test_synthetic_config_md5_on_gpu(hip, name):
+    """The committed md5s are of the *reference's* bytes for these substreams (oracle/gen_golden.py)."""
+    gold = json.load(open(os.path.join(H.GOLDEN, "synth_md5.json")))[name]
+    cfg = CONFIGS[name]
+    idxs = [g["index"] for g in gold["substreams"]]
+    recs = [capi.synth_records(cfg.seed, i, cfg.substream(i)[0], cfg.substream(i)[1]) for i in idxs]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    caps = [capi.encode_bound(n, 0, 1) for n in lens]
+    desc, total = H.make_desc(lens, [cfg.substream(i)[2] for i in idxs], [2] * len(idxs),
+                              H.SUB_FINISH | H.SUB_ALIGN_RBSP, capacities=caps)
+    out, res = hip.encode_batch(desc, records, total)
+    cat = hashlib.md5()
+    for k, g in enumerate(gold["substreams"]):
+        b = _stream_bytes(out, desc, res, k)
+        assert int(res["n_bits"][k]) == g["n_bits"] and hashlib.md5(b.tobytes()).hexdigest() == g["md5"], (name, k)
+        cat.update(b.tobytes())
+    assert cat.hexdigest() == gold["concat_md5"]
+    ddesc = desc.copy(); ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
+    bins, rd = hip.decode_batch(ddesc, records, out)
+    assert np.array_equal(bins, (records >> 15).astype(np.uint8)) and not rd["flags"].any()
+
+
+def test_full_size_c4_round_trip_device_api(hip):
+    """BASELINE config C4 at full size (4096 substreams x 16384 bins) through the device-pointer API:
+    encode -> decode round trip on all 67 M bins, plus oracle byte parity on a sample of substreams."""
+    import torch
+    orc = H.load_oracle()
+    cfg = CONFIGS["C4"]
+    desc, records, total = build_batch(cfg)
+    n = len(desc)
+    t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
+    t_rec = torch.from_numpy(records.view(np.int16)).cuda()
+    t_bytes = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    t_res = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
+    t_bins = torch.zeros(len(records), dtype=torch.uint8, device="cuda")
+    hip.encode_device(n, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res.data_ptr())
+    hip.synchronize()
+    res = t_res.cpu().numpy().view(capi.RESULT_DTYPE)
+    assert not res["flags"].any()
+    ddesc = desc.copy(); ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
+    t_ddesc = torch.from_numpy(ddesc.view(np.uint8)).cuda()
+    t_res2 = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
+    hip.decode_device(n, t_ddesc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_bins.data_ptr(), t_res2.data_ptr())
+    hip.synchronize()
+    res2 = t_res2.cpu().numpy().view(capi.RESULT_DTYPE)
+    assert not res2["flags"].any()
+    want = (t_rec.view(torch.int16) < 0).to(torch.uint8)      # bit 15 of each record
+    assert bool(torch.equal(t_bins, want))
+    out = t_bytes.cpu().numpy()
+    for s in range(0, n, 97):
+        o, nr = int(desc["rec_offset"][s]), int(desc["n_records"][s])
+        b, nbits = orc.encode_records(records[o:o + nr], 32, 2, 3)
+        assert nbits == int(res["n_bits"][s]) and np.array_equal(_stream_bytes(out, desc, res, s), b)
