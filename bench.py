@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mbins/s encode+decode of the CABAC bin codec on synthetic bin buffers
+(BASELINE.json metric; workloads = SURVEY.md §8d configs, entropy_coding_amd/workload.py).
+
+  python bench.py --gpus N --steps K --warmup W [--workload C4]
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one pass of the hot path over one batch: encode every substream of the batch, then decode
+every substream back (two kernel launches), with all inputs already resident in HBM.  One process per
+GPU; substreams are independent, so each rank codes its own shard (weak scaling: the per-GPU batch is
+fixed) with no data-path collective; RCCL is used only for the barrier, the max-over-ranks reduction
+and an (untimed, reported) gather of the per-substream sizes.  Rank 0 prints ONE JSON line.
+
+The oracle / compiled reference are used here only (a) by the cpu_baseline leg and (b) to verify the
+hashes after the timed region — never inside it.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DESC_BYTES, RESULT_BYTES = 32, 8
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--enc-variant", type=int, default=0)
+    ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, desc, records, budget_s):
+    """Reference CPU path timed on this host, 1 thread, on a bounded sample of the same workload.
+    kind 'reference' = the reference's own sources compiled by oracle/Makefile (oracle/_ref);
+    kind 'port' = oracle/cabac_oracle.c when that library is not present."""
+    import helpers as H
+    if H.ref_available():
+        lib, kind = H.load_ref(), "reference"
+    else:
+        lib, kind = H.load_oracle(), "port"
+    n_sub = len(desc)
+    bins_done, t_enc, t_dec = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    s = 0
+    while s < n_sub and (time.perf_counter() - t_start) < budget_s:
+        o, n, qp = int(desc["rec_offset"][s]), int(desc["n_records"][s]), int(desc["qp"][s])
+        rec = records[o:o + n]
+        t0 = time.perf_counter()
+        b, _ = lib.encode_records(rec, qp, 2, 3)
+        t1 = time.perf_counter()
+        rc, bins, _ = lib.decode_records(rec, qp, 2, b, 1)
+        t2 = time.perf_counter()
+        assert rc == 0
+        t_enc += t1 - t0
+        t_dec += t2 - t1
+        bins_done += n
+        s += 1
+    return {
+        "value": round(2 * bins_done / (t_enc + t_dec) / 1e6, 2),
+        "unit": "Mbins/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": "%s substreams 0..%d (%d bins) encode+decode, g++/gcc -O2, 1 thread" % (cfg.name, s - 1, bins_done),
+        "encode_mbins_s": round(bins_done / t_enc / 1e6, 2),
+        "decode_mbins_s": round(bins_done / t_dec / 1e6, 2),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from entropy_coding_amd import capi
+    from entropy_coding_amd.workload import CONFIGS, build_batch
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.workload]
+    n_sub = cfg.n_substreams
+    first = rank * n_sub  # weak scaling: rank r codes substreams [r*n_sub, (r+1)*n_sub) of the same generator
+    desc, records, bytes_total = build_batch(cfg, first=first, count=n_sub)
+    n_bins = int(len(records))
+
+    stream = torch.cuda.current_stream()
+    hip = capi.CabacHip(local_rank, stream=stream.cuda_stream)
+    hip.set_variant(args.enc_variant, args.dec_variant)
+
+    t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
+    t_rec = torch.from_numpy(records.view(np.int16)).cuda()
+    t_bytes = torch.zeros(bytes_total, dtype=torch.uint8, device="cuda")
+    t_res_e = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
+    t_res_d = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
+    t_bins = torch.zeros(n_bins, dtype=torch.uint8, device="cuda")
+
+    def step():
+        hip.encode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res_e.data_ptr())
+        hip.decode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_bins.data_ptr(),
+                          t_res_d.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    hip.profile_enable(2 * args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch kernel durations from HIP events recorded on the launch stream during the timed region
+    prof = hip.profile_read()
+    enc_ms = [ms for k, ms in prof if k == 0]
+    dec_ms = [ms for k, ms in prof if k == 1]
+    enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
+
+    # ---- verification after the timed region: hashes + round trip ------------------------------
+    res_e = t_res_e.cpu().numpy().view(capi.RESULT_DTYPE)
+    res_d = t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)
+    ok = not res_e["flags"].any() and not res_d["flags"].any()
+    want_bins = (t_rec < 0).to(torch.uint8)
+    ok = ok and bool(torch.equal(t_bins, want_bins))
+    out_bytes = int(((res_e["n_bits"].astype(np.int64) + 7) // 8).sum())
+    hash_match = None
+    if rank == 0:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_md5.json")))[cfg.name]
+        host_bytes = t_bytes.cpu().numpy()
+        hash_match = True
+        for g in gold["substreams"]:
+            s = g["index"] - first
+            if 0 <= s < n_sub:
+                o, nb = int(desc["byte_offset"][s]), (int(res_e["n_bits"][s]) + 7) // 8
+                hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
+        del host_bytes
+
+    # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
+    gather_ms = None
+    if world > 1:
+        sizes = t_res_e.view(-1, 2)[:, 0].contiguous()
+        allsz = [torch.empty_like(sizes) for _ in range(world)]
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather(allsz, sizes)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    if rank == 0:
+        total_bins_per_step = 2 * n_bins * world  # N encoded + N decoded, on every rank
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_bins_per_step / (elapsed / args.steps) / 1e6
+        bytes_enc = 2 * n_bins + out_bytes + (DESC_BYTES + RESULT_BYTES) * n_sub
+        bytes_dec = 3 * n_bins + out_bytes + (DESC_BYTES + RESULT_BYTES) * n_sub
+        enc_gbps = bytes_enc / (enc_avg * 1e-3) / 1e9
+        dec_gbps = bytes_dec / (dec_avg * 1e-3) / 1e9
+        dominant = "decode" if dec_avg >= enc_avg else "encode"
+        ach = dec_gbps if dominant == "decode" else enc_gbps
+        line = {
+            "metric": "Mbins/s encode+decode, intra QP%d synthetic bin buffers" % cfg.substream(0)[2],
+            "value": round(value, 2),
+            "unit": "Mbins/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s" % (cfg.name, cfg.baseline_config),
+                "substreams_per_gpu": n_sub,
+                "bins_per_substream": cfg.substream(0)[0] if cfg.b is None else [cfg.a[0], cfg.b[0]],
+                "bins_per_gpu": n_bins,
+                "ctx_permille": cfg.substream(0)[1],
+                "bins_per_step": total_bins_per_step,
+                "sharding": "substreams split across ranks, no data-path collective",
+                "kernel_variants": {"encode": args.enc_variant, "decode": args.dec_variant},
+            },
+            "encode_mbins_s": round(n_bins / (enc_avg * 1e-3) / 1e6, 2),
+            "decode_mbins_s": round(n_bins / (dec_avg * 1e-3) / 1e6, 2),
+            "kernel_ms": {"encode": round(enc_avg, 4), "decode": round(dec_avg, 4)},
+            "bitstream_bytes_per_gpu": out_bytes,
+            "hash_match": bool(hash_match and ok),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dominant,
+                "achieved": round(ach, 3),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 6),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_dec if dominant == "decode" else bytes_enc,
+                "other_kernel": {"kernel": "encode" if dominant == "decode" else "decode",
+                                 "achieved": round(enc_gbps if dominant == "decode" else dec_gbps, 3)},
+            },
+        }
+        if gather_ms is not None:
+            line["sizes_allgather_ms"] = round(gather_ms, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, desc, records, args.cpu_seconds)
+        if not line["hash_match"]:
+            line["error"] = "bitstream hash / round-trip mismatch"
+        print(json.dumps(line))
+    hip.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0 and not (hash_match and ok):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

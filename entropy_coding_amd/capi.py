@@ -23,7 +23,7 @@ EXPORTS = [
     "cabac_hip_last_error", "cabac_hip_set_stream", "cabac_hip_synchronize", "cabac_hip_set_variant",
     "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
     "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
-    "cabac_hip_last_kernel_ms", "cabac_synth_records",
+    "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
 ]
 
 _lib = None
@@ -36,6 +36,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64.so.7; whichever copy is loaded first serves the whole
+        # process (same SONAME), and torch only works with its own.  Load it first so that this
+        # library and torch share ONE HIP runtime (device memory, streams) in python processes.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(build_library())
     L.cabac_hip_encode_bound.restype = ctypes.c_size_t
     L.cabac_hip_encode_bound.argtypes = [ctypes.c_uint64] * 3
@@ -57,6 +64,8 @@ def load_library():
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
     L.cabac_hip_last_kernel_ms.argtypes = [vp]
+    L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
+    L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.cabac_synth_records.restype = None
     L.cabac_synth_records.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, vp]
     _lib = L
@@ -117,6 +126,20 @@ class CabacHip:
 
     def last_kernel_ms(self):
         return float(self.L.cabac_hip_last_kernel_ms(self.h))
+
+    def profile_enable(self, capacity):
+        self._check(self.L.cabac_hip_profile_enable(self.h, capacity))
+        self._prof_cap = capacity
+
+    def profile_read(self):
+        """[(kind, ms)] of the device calls since the last read; kind 0 encode, 1 decode, 2 binarize."""
+        cap = getattr(self, "_prof_cap", 0)
+        kind = np.zeros(max(cap, 1), np.int32)
+        ms = np.zeros(max(cap, 1), np.float32)
+        n = self.L.cabac_hip_profile_read(self.h, kind.ctypes.data, ms.ctypes.data, cap)
+        if n < 0:
+            self._check(n)
+        return list(zip(kind[:n].tolist(), ms[:n].tolist()))
 
     # ---- host-pointer entry points (numpy) --------------------------------------------------
     def encode_batch(self, desc, records, bytes_total, check=True):

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "cabac_hip.h"
 #include "cabac_kernels.h"
@@ -19,6 +20,10 @@ struct cabac_hip_ctx {
   bool timed = false;
   int enc_variant = 0, dec_variant = 0;
   std::string last_error;
+  // per-launch profiling ring (cabac_hip_profile_enable)
+  std::vector<hipEvent_t> prof_ev;  // 2 per slot
+  std::vector<int32_t> prof_kind;
+  uint32_t prof_n = 0;
   // staging for the host-pointer entry points (grown on demand)
   void *d_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[5] = {0, 0, 0, 0, 0};
@@ -62,6 +67,19 @@ int ensure(cabac_hip_ctx *c, int slot, size_t bytes) {
   }
   c->d_cap[slot] = want;
   return CABAC_HIP_OK;
+}
+
+// Event bracket of one launch: the ring slot when profiling is on, else the ctx's single pair.
+struct Bracket {
+  hipEvent_t a, b;
+};
+Bracket bracket_for(cabac_hip_ctx *c, int kind) {
+  if (!c->prof_ev.empty() && c->prof_n < c->prof_kind.size()) {
+    uint32_t i = c->prof_n++;
+    c->prof_kind[i] = kind;
+    return {c->prof_ev[2 * i], c->prof_ev[2 * i + 1]};
+  }
+  return {c->ev_start, c->ev_stop};
 }
 
 struct DeviceGuard {
@@ -125,6 +143,7 @@ void cabac_hip_destroy(cabac_hip_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < 5; i++)
     if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -181,10 +200,11 @@ int cabac_hip_encode_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substr
                             const uint16_t *d_records, uint8_t *d_bytes, cabac_substream_result *d_results) {
   if (!c || (n_sub && (!d_desc || !d_records || !d_bytes || !d_results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
-  HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+  Bracket br = bracket_for(c, 0);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_encode(c->stream, c->enc_variant, n_sub, d_desc, d_records, d_bytes, d_results));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-  c->timed = true;
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 
@@ -194,10 +214,11 @@ int cabac_hip_decode_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substr
   if (!c || (n_sub && (!d_desc || !d_records || !d_bytes || !d_bins || !d_results)))
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
-  HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+  Bracket br = bracket_for(c, 1);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_decode(c->stream, c->dec_variant, n_sub, d_desc, d_records, d_bytes, d_bins, d_results));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-  c->timed = true;
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 
@@ -207,6 +228,36 @@ int cabac_hip_ctx_init_device(cabac_hip_ctx *c, uint32_t n_sub, const int32_t *d
   DeviceGuard g(c->device);
   HIP_TRY(c, cabac::launch_ctx_init(c->stream, n_sub, d_qp, d_init_id, d_state, d_rate));
   return CABAC_HIP_OK;
+}
+
+int cabac_hip_profile_enable(cabac_hip_ctx *c, uint32_t capacity) {
+  if (!c) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+  c->prof_ev.clear();
+  c->prof_kind.clear();
+  c->prof_n = 0;
+  for (uint32_t i = 0; i < 2 * capacity; i++) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    c->prof_ev.push_back(e);
+  }
+  c->prof_kind.assign(capacity, 0);
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_profile_read(cabac_hip_ctx *c, int32_t *kind, float *ms, uint32_t max_entries) {
+  if (!c || !kind || !ms) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint32_t n = c->prof_n < max_entries ? c->prof_n : max_entries;
+  for (uint32_t i = 0; i < n; i++) {
+    kind[i] = c->prof_kind[i];
+    HIP_TRY(c, hipEventElapsedTime(&ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+  }
+  c->prof_n = 0;
+  return (int)n;
 }
 
 float cabac_hip_last_kernel_ms(cabac_hip_ctx *c) {

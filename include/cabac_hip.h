@@ -185,6 +185,15 @@ int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
                            const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
                            uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
 
+/* ---- per-launch timing (HIP events on the ctx stream) ----------------
+ * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize device call is
+ * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
+ * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init) and ms[i] for the recorded calls in launch order,
+ * returns their number and resets the ring.                                 */
+int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
+int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);
+
 /* ---- timing of the last device call (HIP events on the ctx stream) --- */
 /* milliseconds between the events that bracket the kernel(s) of the last
  * encode/decode/binarize device call; <0 if unavailable.  Synchronises.      */
