@@ -1,0 +1,262 @@
+// Host-side C++ mirror of the reference's bin-codec interface, on top of the C ABI (cabac_hip.h).
+//
+// The reference's callers (CABACWriter / CABACReader) talk to the codec through
+//   BinEncIf          entropy_codec/arith_codec.hpp:31-70   (encodeBin, encodeBinEP, encodeBinsEP,
+//                                                             encodeRemAbsEP, encodeBinTrm, align, ...)
+//   BinDecoderBase    entropy_codec/arith_codec.hpp:215-260 (decodeBin, decodeBinEP, decodeBinsEP, ...)
+//   OutputBitstream / InputBitstream   common/bit_stream.hpp:16-168
+// and make 10^4..10^6 tiny virtual calls per frame.  Those cannot cross to the GPU one by one, so
+// BinEncoderHip *records* them as 16-bit bin records (cabac_hip.h) and a HipBatch codes whole
+// substreams on the device; afterwards each substream's OutputBitstream is in exactly the state the
+// reference leaves it in after finish() (same FIFO bytes, same held bits).
+//
+// Names, argument meaning and error behaviour follow the reference (errors are C++ exceptions,
+// type_def.hpp:295-329).  integration/reference_adapter.hpp shows the same recorder deriving from
+// the reference's own BinEncIf for a true drop-in.
+#ifndef CABAC_HIP_HOST_HPP
+#define CABAC_HIP_HOST_HPP
+
+#include <cstdint>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cabac_hip.h"
+
+namespace EntropyCodingAMD {
+
+class Exception : public std::exception {
+public:
+  explicit Exception(std::string s) : m_str(std::move(s)) {}
+  const char *what() const noexcept override { return m_str.c_str(); }
+
+private:
+  std::string m_str;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Byte-stream containers (reference: common/bit_stream.hpp:16-97, :103-168).  Only the members the
+// bin codec and its callers use are mirrored; public data members keep the reference's names.
+class OutputBitstream {
+public:
+  std::vector<uint8_t> m_fifo;
+  uint32_t m_num_held_bits = 0;
+  uint8_t m_held_bits = 0;
+
+  void write(uint32_t uiBits, uint32_t uiNumberOfBits);  // bit_stream.cpp:70-117
+  void writeAlignZero();                                 // :125-132
+  void writeAlignOne();                                  // :119-123
+  void writeByteAlignment();                             // :152-155
+  void addSubstream(OutputBitstream *pcSubstream);       // :139-150
+  void clear();
+  int getNumBitsUntilByteAligned() const { return (8 - m_num_held_bits) & 0x7; }
+  uint32_t getNumberOfWrittenBits() const { return uint32_t(m_fifo.size()) * 8 + m_num_held_bits; }
+  std::vector<uint8_t> &getFIFO() { return m_fifo; }
+  const std::vector<uint8_t> &getFIFO() const { return m_fifo; }
+  uint8_t getHeldBits() const { return m_held_bits; }
+  uint8_t *getByteStream() { return m_fifo.data(); }
+  uint32_t getByteStreamLength() const { return uint32_t(m_fifo.size()); }
+};
+
+class InputBitstream {
+public:
+  std::vector<uint8_t> m_fifo;
+  uint32_t m_fifo_idx = 0;
+
+  std::vector<uint8_t> &getFifo() { return m_fifo; }
+  const std::vector<uint8_t> &getFifo() const { return m_fifo; }
+  uint32_t readByte();                      // bit_stream.cpp:268-274 (throws "FIFO exceeded")
+  void peekPreviousByte(uint32_t &byte);    // :276-279
+  uint32_t getByteLocation() const { return m_fifo_idx; }
+  uint32_t getNumBitsUntilByteAligned() const { return 0; }
+  uint32_t getNumBitsLeft() const { return 8 * (uint32_t(m_fifo.size()) - m_fifo_idx); }
+  InputBitstream *extractSubstream(uint32_t uiNumBits);  // :382-415 (byte-aligned case)
+};
+
+// ---------------------------------------------------------------------------------------------
+// BinCounter (arith_codec.hpp:72-93, arith_codec.cpp:281-316)
+class BinCounter {
+public:
+  BinCounter() : m_NumBinsCtx(CABAC_NUM_CONTEXTS, 0) {}
+  void reset();
+  void addCtx(unsigned ctxId) { m_NumBinsCtx[ctxId]++; }
+  void addEP(unsigned num) { m_NumBinsEP += num; }
+  void addEP() { m_NumBinsEP++; }
+  void addTrm() { m_NumBinsTrm++; }
+  uint32_t getAll() const;
+  uint32_t getCtx(unsigned ctxId) const { return m_NumBinsCtx[ctxId]; }
+  uint32_t getEP() const { return m_NumBinsEP; }
+  uint32_t getTrm() const { return m_NumBinsTrm; }
+
+private:
+  std::vector<uint32_t> m_NumBinsCtx;
+  uint32_t m_NumBinsEP = 0, m_NumBinsTrm = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// A session on one GPU: collects finished substreams and codes them in one launch.
+class HipBatch {
+public:
+  explicit HipBatch(int device = 0);
+  ~HipBatch();
+  HipBatch(const HipBatch &) = delete;
+  HipBatch &operator=(const HipBatch &) = delete;
+
+  // Encode every pending substream and append its bytes to its OutputBitstream.
+  void flush();
+  size_t pending() const { return m_pending.size(); }
+  cabac_hip_ctx *handle();  // initialises the device on first use; throws if there is no GPU
+
+  // Decode: ctx/EP/TRM record sequences against byte-aligned substreams (supplied-ctxId replay).
+  struct DecodeJob {
+    const uint16_t *records;
+    uint32_t n_records;
+    const uint8_t *bytes;
+    uint32_t n_bytes;
+    int qp;
+    int initId;
+    bool finish;
+  };
+  // bins[i] receives the decoded bins of job i; throws Exception on UNDERRUN / BAD_STOP like the
+  // reference's CHECKs ("FIFO exceeded", "No proper stop/alignment pattern ...").
+  void decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
+              std::vector<uint32_t> *bitsRead = nullptr);
+
+  // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
+  // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
+  // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned
+  // in bytes[whole]) exactly as the reference's finish() leaves them.
+  struct Pending {
+    std::vector<uint16_t> records;
+    int qp = 0, initId = 0;
+    uint64_t nCtx = 0, nEp = 0, nTrm = 0;
+    OutputBitstream *sink = nullptr;
+    std::function<void(const uint8_t *bytes, uint32_t whole, uint32_t tail_bits)> deliver;
+  };
+  void submit(Pending &&p) { m_pending.push_back(std::move(p)); }
+
+private:
+  friend class BinEncoderHip;
+  int m_device;
+  cabac_hip_ctx *m_ctx = nullptr;
+  std::vector<Pending> m_pending;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Encoder interface — same virtuals as the reference's BinEncIf (arith_codec.hpp:39-69).
+class BinEncIf {
+public:
+  virtual ~BinEncIf() = default;
+  virtual void init(OutputBitstream *bitstream) = 0;
+  virtual void uninit() = 0;
+  virtual void start() = 0;
+  virtual void finish() = 0;
+  virtual void restart() = 0;
+  virtual void reset(int qp, int initId) = 0;
+  virtual void resetBits() = 0;
+  virtual uint64_t getEstFracBits() const = 0;
+  virtual unsigned getNumBins(unsigned ctxId) const = 0;
+  virtual void encodeBin(unsigned bin, unsigned ctxId) = 0;
+  virtual void encodeBinEP(unsigned bin) = 0;
+  virtual void encodeBinsEP(unsigned bins, unsigned numBins) = 0;
+  virtual void encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) = 0;
+  virtual void encodeBinTrm(unsigned bin) = 0;
+  virtual void align() = 0;
+  virtual uint32_t getNumBins() = 0;
+  virtual bool isEncoding() = 0;
+  virtual unsigned getNumWrittenBits() = 0;
+
+  // Ctx side state the syntax layer reads/writes through the encoder (contexts.hpp:273-274,
+  // contexts.cpp:1147-1166; RExt__GOLOMB_RICE_ADAPTATION_STATISTICS_SETS = 3)
+  unsigned &getGRAdaptStats(unsigned id) { return m_GRAdaptStats[id]; }
+  void riceStatReset(int bitDepth);
+
+protected:
+  unsigned m_GRAdaptStats[3] = {0, 0, 0};
+};
+
+// Recording encoder.  mode Deferred: finish() queues the substream, bytes appear after
+// HipBatch::flush().  mode Immediate: finish() flushes at once (reference semantics, one launch per
+// substream — for drop-in tests, not for throughput).
+class BinEncoderHip : public BinEncIf, public BinCounter {
+public:
+  enum Mode { Deferred, Immediate };
+  explicit BinEncoderHip(HipBatch &batch, Mode mode = Deferred) : m_batch(batch), m_mode(mode) {}
+
+  void init(OutputBitstream *bitstream) override { m_Bitstream = bitstream; }  // arith_codec.cpp:323-325
+  void uninit() override { m_Bitstream = nullptr; }
+  void start() override;                  // arith_codec.cpp:329-337
+  void finish() override;                 // arith_codec.cpp:339-357 (deferred to the device)
+  void restart() override;                // :359-365 — only legal on an empty recording
+  void reset(int qp, int initId) override;  // :367-370
+  void resetBits() override;              // :372-378
+  uint64_t getEstFracBits() const override { throw Exception("not supported"); }  // as :380-383
+  unsigned getNumBins(unsigned ctxId) const override { return BinCounter::getCtx(ctxId); }
+  void encodeBin(unsigned bin, unsigned ctxId) override;
+  void encodeBinEP(unsigned bin) override;
+  void encodeBinsEP(unsigned bins, unsigned numBins) override;
+  void encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) override;
+  void encodeBinTrm(unsigned bin) override;
+  void align() override;
+  uint32_t getNumBins() override { return BinCounter::getAll(); }
+  bool isEncoding() override { return true; }
+  // Mid-stream arithmetic state lives on the device only; the reference uses this call solely in
+  // the window-size training helper estBits (cabac_writer.cpp:83-96), which is out of scope.
+  unsigned getNumWrittenBits() override { throw Exception("getNumWrittenBits: not available from a recording encoder"); }
+
+  const std::vector<uint16_t> &records() const { return m_records; }
+
+private:
+  void put(unsigned id, unsigned bin) { m_records.push_back(uint16_t(id | (bin ? CABAC_REC_BIN : 0u))); }
+  HipBatch &m_batch;
+  Mode m_mode;
+  OutputBitstream *m_Bitstream = nullptr;
+  std::vector<uint16_t> m_records;
+  int m_qp = 0, m_initId = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Binarisation helpers of the syntax layer (private members of CABACWriter in the reference,
+// cabac_writer.cpp:3072-3118, :854-882) as free functions over any BinEncIf.
+void unary_max_symbol(BinEncIf &e, unsigned symbol, unsigned ctxId0, unsigned ctxIdN, unsigned maxSymbol);
+void unary_max_eqprob(BinEncIf &e, unsigned symbol, unsigned maxSymbol);
+void exp_golomb_eqprob(BinEncIf &e, unsigned symbol, unsigned count);
+void xWriteTruncBinCode(BinEncIf &e, uint32_t symbol, uint32_t maxSymbol);
+
+// ---------------------------------------------------------------------------------------------
+// Replay decoder: the ctxId/EP/TRM sequence is planned first (plan*), decoded in one launch
+// (run), then served through the BinDecoderBase-shaped calls, which verify that the caller asks
+// for exactly the planned sequence.  (A real syntax walk chooses ctxIds from decoded values —
+// that feedback is the "next" row f2 of SURVEY.md §8; this class covers the supplied-ctxId path.)
+class BinDecoderHip {
+public:
+  explicit BinDecoderHip(HipBatch &batch) : m_batch(batch) {}
+  void init(InputBitstream *bitstream) { m_Bitstream = bitstream; }  // arith_codec.cpp:54-56
+  void uninit() { m_Bitstream = nullptr; }
+  void reset(int qp, int initId);                                      // :75-78
+  void planBin(unsigned ctxId) { m_plan.push_back(uint16_t(ctxId)); }
+  void planBinEP(unsigned n = 1) { m_plan.insert(m_plan.end(), n, uint16_t(CABAC_REC_EP)); }
+  void planBinTrm() { m_plan.push_back(uint16_t(CABAC_REC_TRM)); }
+  void run(bool checkFinish);
+
+  unsigned decodeBin(unsigned ctxId);          // :242-277
+  unsigned decodeBinEP();                      // :100-114
+  unsigned decodeBinsEP(unsigned numBins);     // :116-151
+  unsigned decodeBinTrm();                     // :181-197
+  unsigned getNumBitsRead() const { return m_bitsRead; }  // :201-203
+
+private:
+  unsigned next(unsigned id);
+  HipBatch &m_batch;
+  InputBitstream *m_Bitstream = nullptr;
+  std::vector<uint16_t> m_plan;
+  std::vector<uint8_t> m_bins;
+  size_t m_pos = 0;
+  int m_qp = 0, m_initId = 0;
+  uint32_t m_bitsRead = 0;
+};
+
+}  // namespace EntropyCodingAMD
+#endif

@@ -1,0 +1,117 @@
+// TEST INFRASTRUCTURE.  Runs the reference's OWN CABACWriter (cabac_writer.hpp) on top of
+// BinEncoderHipRef (the GPU recording encoder) and, side by side, on top of the reference's
+// BinEncoder_Std, from the same op stream; returns both byte strings so the test can compare them.
+// Built by oracle/Makefile into oracle/_ref/libadapter_test.so (needs the reference headers and
+// objects, so it is built in the build container only; the .so travels to the GPU box).
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#define private public
+#define protected public
+#include "cabac_writer.hpp"
+#undef private
+#undef protected
+#include "reference_adapter.hpp"
+
+using namespace EntropyCoding;
+using namespace Common;
+
+enum { OP_BIN = 0, OP_EP, OP_BINS_EP, OP_REM_ABS, OP_TRM, OP_ALIGN, OP_UNARY_MAX, OP_UNARY_EP, OP_EXP_GOLOMB, OP_TRUNC_BIN };
+
+static thread_local char g_err[512];
+
+static void drive(CABACWriter &w, BinEncIf &e, const uint32_t *ops, long n) {
+  for (long i = 0; i < n; i++) {
+    const uint32_t *o = ops + 4 * i;
+    switch (o[0]) {
+    case OP_BIN: e.encodeBin(o[1], o[2]); break;
+    case OP_EP: e.encodeBinEP(o[1]); break;
+    case OP_BINS_EP: e.encodeBinsEP(o[1], o[2]); break;
+    case OP_REM_ABS: e.encodeRemAbsEP(o[1], o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+    case OP_TRM: e.encodeBinTrm(o[1]); break;
+    case OP_ALIGN: e.align(); break;
+    case OP_UNARY_MAX: w.unary_max_symbol(o[1], o[2] & 0xffff, o[2] >> 16, o[3]); break;  // reference's binarisers
+    case OP_UNARY_EP: w.unary_max_eqprob(o[1], o[2]); break;
+    case OP_EXP_GOLOMB: w.exp_golomb_eqprob(o[1], o[2]); break;
+    case OP_TRUNC_BIN: w.xWriteTruncBinCode(o[1], o[2]); break;
+    }
+  }
+}
+
+static long dump(OutputBitstream &bs, uint8_t *out, long cap, uint32_t *nbits) {
+  *nbits = bs.getNumberOfWrittenBits();
+  long n = (long)bs.getFIFO().size(), total = n + ((*nbits & 7) ? 1 : 0);
+  if (total > cap) return -3;
+  if (n) memcpy(out, bs.getFIFO().data(), n);
+  if (*nbits & 7) out[n] = bs.getHeldBits();
+  return total;
+}
+
+extern "C" {
+const char *adapter_last_error() { return g_err; }
+
+// which = 0: reference BinEncoder_Std; 1: BinEncoderHipRef (GPU).  Both under the reference CABACWriter,
+// ending with the reference's end_of_slice() (TRM(1) + finish()) and VTM's writeByteAlignment().
+long adapter_encode(int which, const uint32_t *ops, long n_ops, int qp, int initId, uint8_t *out, long cap,
+                    uint32_t *nbits, uint32_t *numBins) {
+  try {
+    OutputBitstream bs;
+    if (which == 0) {
+      BinEncoder_Std enc;
+      CABACWriter w(enc);
+      w.initBitstream(&bs);
+      enc.reset(qp, initId);
+      drive(w, enc, ops, n_ops);
+      w.end_of_slice();
+      *numBins = w.getNumBins();
+    } else {
+      EntropyCodingAMD::HipBatch batch(0);
+      EntropyCodingAMD::BinEncoderHipRef enc(batch);
+      CABACWriter w(enc);
+      w.initBitstream(&bs);
+      enc.reset(qp, initId);
+      drive(w, enc, ops, n_ops);
+      w.end_of_slice();
+      *numBins = w.getNumBins();
+      batch.flush();
+    }
+    bs.writeByteAlignment();
+    return dump(bs, out, cap, nbits);
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+// CPU only: what the adapter recorded under the reference's CABACWriter
+long adapter_record(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, uint32_t *numBins) {
+  try {
+    EntropyCodingAMD::HipBatch batch(0);
+    EntropyCodingAMD::BinEncoderHipRef enc(batch);
+    OutputBitstream bs;
+    CABACWriter w(enc);
+    w.initBitstream(&bs);
+    enc.reset(32, 2);
+    drive(w, enc, ops, n_ops);
+    *numBins = w.getNumBins();
+    long n = (long)enc.records().size();
+    if (n > cap) return -3;
+    if (n) memcpy(rec, enc.records().data(), n * 2);
+    return n;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+}

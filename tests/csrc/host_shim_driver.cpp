@@ -1,0 +1,150 @@
+// Test driver: C entry points that drive the C++ host shim (entropy_coding_amd/host) the way the
+// reference's CABACWriter/CABACReader drive BinEncIf/BinDecoderBase, from the shared op stream
+// format of the oracle (oracle/cabac_oracle.h).  Built by tests/test_host_shim.py with g++.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "cabac_hip_host.hpp"
+
+using namespace EntropyCodingAMD;
+
+enum { OP_BIN = 0, OP_EP, OP_BINS_EP, OP_REM_ABS, OP_TRM, OP_ALIGN, OP_UNARY_MAX, OP_UNARY_EP, OP_EXP_GOLOMB, OP_TRUNC_BIN };
+
+static thread_local char g_err[512];
+
+static void apply_ops(BinEncIf &e, const uint32_t *ops, long n) {
+  for (long i = 0; i < n; i++) {
+    const uint32_t *o = ops + 4 * i;
+    switch (o[0]) {
+    case OP_BIN: e.encodeBin(o[1], o[2]); break;
+    case OP_EP: e.encodeBinEP(o[1]); break;
+    case OP_BINS_EP: e.encodeBinsEP(o[1], o[2]); break;
+    case OP_REM_ABS: e.encodeRemAbsEP(o[1], o[2], o[3] & 0xff, int(o[3] >> 8)); break;
+    case OP_TRM: e.encodeBinTrm(o[1]); break;
+    case OP_ALIGN: e.align(); break;
+    case OP_UNARY_MAX: unary_max_symbol(e, o[1], o[2] & 0xffff, o[2] >> 16, o[3]); break;
+    case OP_UNARY_EP: unary_max_eqprob(e, o[1], o[2]); break;
+    case OP_EXP_GOLOMB: exp_golomb_eqprob(e, o[1], o[2]); break;
+    case OP_TRUNC_BIN: xWriteTruncBinCode(e, o[1], o[2]); break;
+    default: throw Exception("bad op");
+    }
+  }
+}
+
+extern "C" {
+
+const char *shim_last_error() { return g_err; }
+
+// CPU only: ops -> recorded bin records + BinCounter totals {ctx, EP, TRM, getNumBins()}
+long shim_record_ops(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, uint32_t *counts) {
+  try {
+    HipBatch batch(0);  // never touches the device while only recording
+    BinEncoderHip enc(batch);
+    OutputBitstream bs;
+    enc.init(&bs);
+    enc.reset(32, 2);
+    apply_ops(enc, ops, n_ops);
+    const std::vector<uint16_t> &r = enc.records();
+    if ((long)r.size() > cap) return -3;
+    if (!r.empty()) memcpy(rec, r.data(), r.size() * 2);
+    counts[1] = enc.getEP();
+    counts[2] = enc.getTrm();
+    counts[3] = static_cast<BinEncIf &>(enc).getNumBins();
+    counts[0] = counts[3] - counts[1] - counts[2];
+    return (long)r.size();
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+// GPU: n_streams op streams through n_streams BinEncoderHip objects sharing one HipBatch.
+// mode 0: Deferred (one launch for all), 1: Immediate (finish() codes at once).
+// flags bit1: caller appends writeByteAlignment() afterwards, as VTM does.
+// out: streams packed back to back at out_off[s]; n_bits[s] = getNumberOfWrittenBits().
+int shim_encode_streams(int n_streams, const uint32_t *ops, const long *op_off, const int *qp, const int *init_id,
+                        int mode, int flags, uint8_t *out, const long *out_off, uint32_t *n_bits) {
+  try {
+    HipBatch batch(0);
+    std::vector<std::unique_ptr<BinEncoderHip>> enc;
+    std::vector<OutputBitstream> bs(n_streams);
+    for (int s = 0; s < n_streams; s++) {
+      enc.emplace_back(new BinEncoderHip(batch, mode ? BinEncoderHip::Immediate : BinEncoderHip::Deferred));
+      BinEncIf &e = *enc.back();
+      e.init(&bs[s]);
+      e.reset(qp[s], init_id[s]);
+      apply_ops(e, ops + 4 * op_off[s], op_off[s + 1] - op_off[s]);
+      e.encodeBinTrm(1);  // end_of_slice(), cabac_writer.cpp:104-107
+      e.finish();
+    }
+    batch.flush();
+    for (int s = 0; s < n_streams; s++) {
+      if (flags & 2) bs[s].writeByteAlignment();
+      n_bits[s] = bs[s].getNumberOfWrittenBits();
+      long cap = out_off[s + 1] - out_off[s];
+      long need = (long)bs[s].m_fifo.size() + (bs[s].m_num_held_bits ? 1 : 0);
+      if (need > cap) return -3;
+      if (!bs[s].m_fifo.empty()) memcpy(out + out_off[s], bs[s].m_fifo.data(), bs[s].m_fifo.size());
+      if (bs[s].m_num_held_bits) out[out_off[s] + bs[s].m_fifo.size()] = bs[s].m_held_bits;
+    }
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+// GPU: replay-decode one substream: plan the record ids, run, then pull every bin back through the
+// BinDecoderBase-shaped calls.  Returns 0, or -1 with shim_last_error() (e.g. "FIFO exceeded").
+int shim_decode_replay(const uint16_t *rec, long n, int qp, int init_id, const uint8_t *bytes, long n_bytes,
+                       int check_finish, uint8_t *bins, uint32_t *fifo_idx_after) {
+  try {
+    HipBatch batch(0);
+    BinDecoderHip dec(batch);
+    InputBitstream ib;
+    ib.getFifo().assign(bytes, bytes + n_bytes);
+    dec.init(&ib);
+    dec.reset(qp, init_id);
+    for (long i = 0; i < n; i++) {
+      unsigned id = rec[i] & CABAC_REC_ID_MASK;
+      if (id < CABAC_NUM_CONTEXTS) dec.planBin(id);
+      else if (id == CABAC_REC_EP) dec.planBinEP();
+      else if (id == CABAC_REC_TRM) dec.planBinTrm();
+      else throw Exception("bad record");
+    }
+    dec.run(check_finish != 0);
+    for (long i = 0; i < n; i++) {
+      unsigned id = rec[i] & CABAC_REC_ID_MASK;
+      bins[i] = (uint8_t)(id < CABAC_NUM_CONTEXTS ? dec.decodeBin(id) : id == CABAC_REC_EP ? dec.decodeBinEP() : dec.decodeBinTrm());
+    }
+    *fifo_idx_after = ib.getByteLocation();
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+// CPU only: OutputBitstream mirror behaviour: sequence of (bits, nbits) writes then optional alignment
+long shim_bitstream_writes(const uint32_t *vals, const uint32_t *nbits, long n, int align, uint8_t *out, long cap,
+                           uint32_t *total_bits) {
+  try {
+    OutputBitstream bs, outer;
+    for (long i = 0; i < n; i++) bs.write(vals[i], nbits[i]);
+    outer.write(5, 3);          // non-aligned parent, then addSubstream (bit_stream.cpp:139-150)
+    outer.addSubstream(&bs);
+    if (align) outer.writeByteAlignment();
+    *total_bits = outer.getNumberOfWrittenBits();
+    long need = (long)outer.m_fifo.size() + (outer.m_num_held_bits ? 1 : 0);
+    if (need > cap) return -3;
+    if (!outer.m_fifo.empty()) memcpy(out, outer.m_fifo.data(), outer.m_fifo.size());
+    if (outer.m_num_held_bits) out[outer.m_fifo.size()] = outer.m_held_bits;
+    return need;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+}

@@ -1,0 +1,165 @@
+"""The C++ host shim (entropy_coding_amd/host: BinEncoderHip / BinDecoderHip / HipBatch / bitstream
+mirrors), driven like the reference's CABACWriter drives BinEncIf.  CPU tests cover the recording and
+container logic; GPU tests cover the full path shim -> C ABI -> HIP kernels against the oracle and the
+reference-generated golden vectors."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+CSRC = os.path.join(H.ROOT, "tests", "csrc")
+u8p, u16p, u32p = H.u8p, H.u16p, H.u32p
+lp = ctypes.POINTER(ctypes.c_long)
+ip = ctypes.POINTER(ctypes.c_int)
+
+
+@pytest.fixture(scope="module")
+def drv():
+    from entropy_coding_amd import capi
+    capi.load_library()          # builds libcabac_hip.so if stale (and loads torch's HIP runtime first)
+    so = os.path.join(CSRC, "libhost_shim_driver.so")
+    src = os.path.join(CSRC, "host_shim_driver.cpp")
+    lib = os.path.join(H.ROOT, "entropy_coding_amd", "libcabac_hip.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(H.ROOT, "include"),
+                               "-I" + os.path.join(H.ROOT, "entropy_coding_amd", "host"), src,
+                               "-L" + os.path.dirname(lib), "-lcabac_hip", "-Wl,-rpath," + os.path.dirname(lib),
+                               "-o", so])
+    L = ctypes.CDLL(so)
+    L.shim_last_error.restype = ctypes.c_char_p
+    L.shim_record_ops.restype = ctypes.c_long
+    L.shim_record_ops.argtypes = [u32p, ctypes.c_long, u16p, ctypes.c_long, u32p]
+    L.shim_encode_streams.argtypes = [ctypes.c_int, u32p, lp, ip, ip, ctypes.c_int, ctypes.c_int, u8p, lp, u32p]
+    L.shim_decode_replay.argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_long,
+                                     ctypes.c_int, u8p, u32p]
+    L.shim_bitstream_writes.restype = ctypes.c_long
+    L.shim_bitstream_writes.argtypes = [u32p, u32p, ctypes.c_long, ctypes.c_int, u8p, ctypes.c_long, u32p]
+    return L
+
+
+def _record(drv, ops):
+    ops = np.ascontiguousarray(ops, np.uint32)
+    rec = np.zeros(40 * len(ops) + 8, np.uint16)
+    counts = np.zeros(4, np.uint32)
+    n = drv.shim_record_ops(H._ptr(ops, u32p), len(ops), H._ptr(rec, u16p), len(rec), H._ptr(counts, u32p))
+    assert n >= 0, drv.shim_last_error()
+    return rec[:n], counts
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_recorder_matches_oracle_binarisation(drv, seed):
+    """BinEncoderHip + helper binarisers record exactly the bin sequence the oracle's expander gives,
+    and BinCounter totals equal the reference's (arith_codec.cpp:281-316)."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(50 + seed)
+    ops = H.random_ops(rng, 3000, ctx_frac=[0.0, 0.4, 0.8][seed % 3], with_align=(seed == 5))
+    rec, counts = _record(drv, ops)
+    want = orc.ops_to_records(ops)
+    assert np.array_equal(rec, want)
+    _, _, nbins = orc.encode_ops(ops, 32, 2, 1)
+    assert list(counts[:3]) == list(nbins) and counts[3] == nbins.sum()
+
+
+def test_recorder_golden_counts(drv):
+    gold = np.load(os.path.join(H.GOLDEN, "vectors.npz"))
+    for k in range(int(gold["n_cases"][0])):
+        rec, counts = _record(drv, gold["case%d_ops" % k])
+        assert list(counts[:3]) == list(gold["case%d_nbins" % k])     # the reference's own BinCounter values
+
+
+def test_recorder_rejects_bad_arguments(drv):
+    for bad in ([H.OP_BIN, 1, 379, 0], [H.OP_BINS_EP, 4, 2, 0], [H.OP_UNARY_MAX, 5, 0, 3], [H.OP_TRUNC_BIN, 7, 7, 0]):
+        ops = np.array([bad], np.uint32)
+        rec = np.zeros(64, np.uint16)
+        counts = np.zeros(4, np.uint32)
+        assert drv.shim_record_ops(H._ptr(ops, u32p), 1, H._ptr(rec, u16p), 64, H._ptr(counts, u32p)) == -1
+        assert b"ERROR" in drv.shim_last_error()
+
+
+def test_output_bitstream_mirror(drv):
+    """write / addSubstream into a non-aligned parent / writeByteAlignment (bit_stream.cpp:70-155)."""
+    rng = np.random.default_rng(3)
+    for trial in range(50):
+        n = int(rng.integers(0, 40))
+        nb = rng.integers(0, 33, size=n).astype(np.uint32)
+        vals = np.array([int(rng.integers(0, 1 << 32)) & ((1 << int(b)) - 1) if b else 0 for b in nb], np.uint32)
+        align = trial & 1
+        out = np.zeros(4 * n + 16, np.uint8)
+        tb = ctypes.c_uint32()
+        got = drv.shim_bitstream_writes(H._ptr(vals, u32p), H._ptr(nb, u32p), n, align, H._ptr(out, u8p), len(out),
+                                        ctypes.byref(tb))
+        bits = "101" + "".join(format(int(v), "0%db" % int(b)) if b else "" for v, b in zip(vals, nb))
+        if align:
+            bits += "1"
+            bits += "0" * (-len(bits) % 8)
+        assert tb.value == len(bits)
+        padded = bits + "0" * (-len(bits) % 8)
+        want = bytes(int(padded[i:i + 8], 2) for i in range(0, len(padded), 8))
+        assert got == len(want) and out[:got].tobytes() == want
+
+
+# ------------------------------------------------------------------ GPU
+def _encode_streams(drv, op_list, qps, ids, mode, flags):
+    n = len(op_list)
+    ops = np.concatenate(op_list).astype(np.uint32)
+    op_off = np.concatenate([[0], np.cumsum([len(o) for o in op_list])]).astype(np.int64)
+    caps = [64 + 6 * len(o) * 5 for o in op_list]
+    out_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
+    out = np.zeros(int(out_off[-1]), np.uint8)
+    nbits = np.zeros(n, np.uint32)
+    rc = drv.shim_encode_streams(n, H._ptr(ops, u32p), op_off.ctypes.data_as(lp),
+                                 np.asarray(qps, np.int32).ctypes.data_as(ip), np.asarray(ids, np.int32).ctypes.data_as(ip),
+                                 mode, flags, H._ptr(out, u8p), out_off.ctypes.data_as(lp), H._ptr(nbits, u32p))
+    assert rc == 0, drv.shim_last_error()
+    return [out[int(out_off[s]):int(out_off[s]) + (int(nbits[s]) + 7) // 8] for s in range(n)], nbits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shim_encode_matches_oracle(drv, mode):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(70 + mode)
+    op_list = [H.random_ops(rng, int(n), ctx_frac=0.6, end_trm=False) for n in rng.integers(0, 1500, size=12)]
+    qps, ids = rng.integers(0, 64, size=12), rng.integers(0, 3, size=12)
+    for flags in (0, 2):
+        got, nbits = _encode_streams(drv, op_list, qps, ids, mode, flags)
+        for s, ops in enumerate(op_list):
+            full = np.concatenate([ops.reshape(-1, 4), np.array([[H.OP_TRM, 1, 0, 0]], np.uint32)])
+            want, wbits, _ = orc.encode_ops(full, int(qps[s]), int(ids[s]), 1 | flags)
+            assert wbits == nbits[s] and np.array_equal(got[s], want), s
+
+
+@pytest.mark.gpu
+def test_shim_encode_matches_reference_golden(drv):
+    """Golden op streams end with TRM(1) themselves; strip it (the driver adds end_of_slice)."""
+    gold = np.load(os.path.join(H.GOLDEN, "vectors.npz"))
+    ks = [k for k in range(int(gold["n_cases"][0])) if len(gold["case%d_ops" % k])]
+    op_list = [gold["case%d_ops" % k][:-1] for k in ks]
+    metas = [[int(x) for x in gold["case%d_meta" % k]] for k in ks]
+    got, nbits = _encode_streams(drv, op_list, [m[0] for m in metas], [m[1] for m in metas], 0, 2)
+    for i, k in enumerate(ks):
+        assert nbits[i] == metas[i][2] and np.array_equal(got[i], gold["case%d_bytes_aligned" % k]), k
+
+
+@pytest.mark.gpu
+def test_shim_decode_replay(drv):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(91)
+    rec = H.random_records(rng, 5000)
+    data, nbits = orc.encode_records(rec, 27, 2, 3)
+    tail = np.array([1, 2, 3], np.uint8)                       # following bytes must stay unread
+    buf = np.concatenate([data, tail])
+    bins = np.zeros(len(rec), np.uint8)
+    idx = ctypes.c_uint32()
+    rc = drv.shim_decode_replay(H._ptr(rec, u16p), len(rec), 27, 2, H._ptr(buf, u8p), len(buf), 1, H._ptr(bins, u8p),
+                                ctypes.byref(idx))
+    assert rc == 0, drv.shim_last_error()
+    assert np.array_equal(bins, (rec >> 15).astype(np.uint8)) and idx.value == len(data)
+    # reference error behaviour: truncated input throws "FIFO exceeded"
+    rc = drv.shim_decode_replay(H._ptr(rec, u16p), len(rec), 27, 2, H._ptr(buf, u8p), len(data) // 2, 1,
+                                H._ptr(bins, u8p), ctypes.byref(idx))
+    assert rc == -1 and b"FIFO exceeded" in drv.shim_last_error()
