@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo processes run scatter -> per-rank encode -> gather.
+The per-rank codec is injected: here the oracle stands in for the GPU (tests may use the oracle);
+on the GPU box the same functions run with CabacHip.encode_batch over RCCL (bench.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import helpers as H
+from entropy_coding_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_batch():
+    rng = np.random.default_rng(42)
+    lens = [int(x) for x in rng.integers(1, 3000, size=23)] + [20000, 1, 64]
+    recs = [H.random_records(rng, n - 1) for n in lens]
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), [2] * len(lens), H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    return desc, np.concatenate(recs), total
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = H.load_oracle()
+    desc, records, total = _make_batch() if rank == 0 else (None, None, 0)
+    got = sharding.encode_sharded(desc, records, lambda d, r, t: orc.encode_batch(d, r, t), root=0)
+    if rank == 0:
+        streams, n_bits = got
+        out, res = orc.encode_batch(desc, records, total)
+        ok = True
+        for s in range(len(desc)):
+            nb = (int(res["n_bits"][s]) + 7) // 8
+            o = int(desc["byte_offset"][s])
+            ok = ok and n_bits[s] == res["n_bits"][s] and np.array_equal(streams[s], out[o:o + nb])
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_encode_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_lpt_assign_balances_mixed_lengths():
+    # C5-like mix: half 2 048-bin and half 262 144-bin substreams
+    n = np.array([2048, 262144] * 64)
+    owners = sharding.lpt_assign(n, 8)
+    loads = [int(n[o].sum()) for o in owners]
+    assert sorted(sum(owners, [])) == list(range(len(n)))
+    assert max(loads) - min(loads) <= 2048 * 8
