@@ -104,7 +104,8 @@ def main():
     n_sub = cfg.n_substreams
     first = rank * n_sub  # weak scaling: rank r codes substreams [r*n_sub, (r+1)*n_sub) of the same generator
     desc, records, bytes_total = build_batch(cfg, first=first, count=n_sub)
-    n_bins = int(len(records))
+    n_bins = int(desc["n_records"].astype(np.int64).sum())
+    n_slots = int(len(records))  # records/bins buffers include the stagger gaps (never touched)
 
     stream = torch.cuda.current_stream()
     hip = capi.CabacHip(local_rank, stream=stream.cuda_stream)
@@ -115,7 +116,7 @@ def main():
     t_bytes = torch.zeros(bytes_total, dtype=torch.uint8, device="cuda")
     t_res_e = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
     t_res_d = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
-    t_bins = torch.zeros(n_bins, dtype=torch.uint8, device="cuda")
+    t_bins = torch.zeros(n_slots, dtype=torch.uint8, device="cuda")
 
     def step():
         hip.encode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res_e.data_ptr())

@@ -510,6 +510,409 @@ __global__ __launch_bounds__(64) void decode_kernel_v1(uint32_t n_sub, const cab
   }
 }
 
+// ==========================================================================================
+// v2 "lane-per-substream": every lane walks its own substream with ordinary per-lane (VALU)
+// arithmetic; a workgroup is ONE wave of L <= 32 active lanes, L chosen at launch.  Why: v1's chain is
+// ~50 *scalar* instructions per bin and a CU has a single scalar issue port shared by all its waves,
+// so with 16 waves per CU (C4: 4 096 substreams) each wave gets one instruction per ~16 cycles.
+// SIMT rules shape the code: different substreams take the LPS / bypass / terminate / byte-output
+// paths at different times, so every record type goes through ONE branch-free sequence (selects,
+// not branches); the only real branches are the rare ones (byte output, refill, align).
+//   * bypass  == a context bin with LPS width t = 0 (range untouched) plus a 1-bit post shift;
+//   * terminate == a context bin with t = 2 and "LPS" == bin: clz(2) - 23 = 7 gives exactly the
+//     7-bit renormalisation and range = 2 << 7 of encodeBinTrm(1) (arith_codec.cpp:460-478).
+// Per-lane context store in LDS: 381 words (379 + a dummy slot that absorbs the always-executed
+// read/write of non-context records; odd stride spreads lanes over banks);
+// word = state0[14:5] | rate bits[4:0] | state1 << 16, rate bits [1:0] = rate0 - 2, [4:2] = rate1 - 5
+// (rate1 <= 9 is CHECKed by the reference, contexts.cpp:919).  The rate bits ride along untouched
+// because every update term is masked.
+constexpr int kLaneStride = 381;
+constexpr uint32_t kDummySlot = 379;
+
+__device__ __forceinline__ uint32_t ctx2_init(int qp, uint32_t init_value, uint32_t w) {
+  uint32_t st = ctx_init_state(qp, init_value);
+  uint32_t r = ctx_init_rates(w);
+  uint32_t r0 = r & 0xffu, r1 = r >> 8;
+  return st | (r0 - 2u) | ((r1 - 5u) << 2);
+}
+
+// q8 = state() of the packed word (contexts.cpp:939-941)
+__device__ __forceinline__ uint32_t ctx2_q8(uint32_t st) { return (((st & kMask0) + (st >> 16)) >> 8) & 0xffu; }
+
+// (q folded to 0..127) >> 2, contexts.cpp:945-949
+__device__ __forceinline__ uint32_t ctx2_k(uint32_t q8) {
+  const uint32_t x = (uint32_t)((int32_t)(q8 << 24) >> 31);  // 0 or ~0 from bit 7
+  return ((q8 ^ x) >> 2) & 31u;
+}
+
+__device__ __forceinline__ uint32_t ctx2_update(uint32_t st, uint32_t bin) {
+  const uint32_t r0 = (st & 3u) + 2u, r1 = ((st >> 2) & 7u) + 5u;
+  const uint32_t s0 = st & kMask0, s1 = st >> 16;
+  const uint32_t d = ((s0 >> r0) & kMask0) | (((s1 >> r1) & kMask1) << 16);
+  const uint32_t a = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
+  return st - d + (bin ? a : 0u);  // halves never borrow/carry into each other (15-bit estimators)
+}
+
+__device__ __forceinline__ void lane_ctx_init(uint32_t *ctx, int qp_in, uint32_t iid) {
+  const int qp = qp_in < 0 ? 0 : (qp_in > 63 ? 63 : qp_in);
+  for (int k = 0; k < kNumCtx; k++)
+    ctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+  ctx[kDummySlot] = 0;
+}
+
+// per-lane byte sink: 4 bytes assembled in a register, stored as one dword
+struct LaneSink {
+  uint8_t *dst;
+  uint32_t cap, pos, cur;
+};
+
+__device__ __forceinline__ void lane_put(LaneSink &s, uint32_t byte) {
+  const uint32_t p = s.pos;
+  s.cur |= (byte & 0xffu) << (8u * (p & 3u));
+  if ((p & 3u) == 3u) {
+    const uint32_t off = p & ~3u;
+    if (off + 4u <= s.cap) {
+      *reinterpret_cast<uint32_t *>(s.dst + off) = s.cur;
+    } else {
+      for (uint32_t b = 0; b < 4; b++)
+        if (off + b < s.cap) s.dst[off + b] = (uint8_t)(s.cur >> (8 * b));
+    }
+    s.cur = 0;
+  }
+  s.pos = p + 1;
+}
+
+__device__ __forceinline__ void lane_sink_finish(LaneSink &s) {
+  const uint32_t p = s.pos, off = p & ~3u;
+  for (uint32_t b = 0; b < (p & 3u); b++)
+    if (off + b < s.cap) s.dst[off + b] = (uint8_t)(s.cur >> (8 * b));
+}
+
+// writeOut, arith_codec.cpp:524-546 (per lane; selects except for the actual byte output)
+__device__ __forceinline__ void lane_write_out(EncState &e, LaneSink &s) {
+  const uint32_t lead = e.low >> (24 - e.bits_left);
+  e.bits_left += 8;
+  e.low &= 0xffffffffu >> e.bits_left;
+  const bool is_ff = lead == 0xffu;
+  const bool emit = !is_ff && e.num_buffered > 0;
+  const uint32_t carry = lead >> 8;
+  const uint32_t first = e.buffered_byte + carry;
+  const int32_t fill_n = e.num_buffered - 1;
+  e.buffered_byte = is_ff ? e.buffered_byte : (lead & 0xffu);
+  e.num_buffered = is_ff ? e.num_buffered + 1 : 1;
+  if (emit) {
+    lane_put(s, first);
+    for (int32_t k = 0; k < fill_n; k++) lane_put(s, 0xffu + carry);
+  }
+}
+
+__device__ __forceinline__ void lane_encode_record(uint32_t r, uint32_t *ctx, EncState &e, LaneSink &sink, uint32_t &bad) {
+  const uint32_t id = r & CABAC_REC_ID_MASK;
+  const uint32_t bin = (r >> 15) & 1u;
+  const bool is_ctx = id < (uint32_t)kNumCtx;
+  const bool is_ep = id == CABAC_REC_EP;
+  const bool is_trm = id == CABAC_REC_TRM;
+  const uint32_t slot = is_ctx ? id : kDummySlot;
+  const uint32_t st = ctx[slot];
+  const uint32_t q8 = ctx2_q8(st);
+  const uint32_t mps = q8 >> 7;
+  const uint32_t k = is_ctx ? ctx2_k(q8) : 0u;
+  const uint32_t c = is_ctx ? 4u : (is_trm ? 2u : 0u);
+  const uint32_t t = (((e.range >> 5) * k) >> 1) + c;            // LPS width (getLPS, contexts.cpp:945-950)
+  const bool lps_path = is_ctx ? (bin != mps) : (is_trm && bin);
+  const uint32_t rm = e.range - t;
+  const int nl = __builtin_clz(t | 1u) - 23;                     // getRenormBitsLPS; unused when t == 0
+  const int nm = rm < 256u ? 1 : 0;
+  const int n = lps_path ? nl : nm;
+  e.low = (e.low + (lps_path ? rm : 0u)) << n;
+  e.range = (lps_path ? t : rm) << n;
+  // bypass: low = (low << 1) + bin * range (encodeBinEP, arith_codec.cpp:389-399)
+  const uint32_t ep = is_ep ? 1u : 0u;
+  e.low = (e.low << ep) + ((is_ep && bin) ? e.range : 0u);
+  if (id == CABAC_REC_ALIGN) e.range = 256;                      // align(), :480
+  bad |= (!is_ctx && id < CABAC_REC_ALIGN) ? 1u : 0u;
+  ctx[slot] = ctx2_update(st, bin);
+  e.bits_left -= n + (int)ep;
+  if (e.bits_left < 12) lane_write_out(e, sink);
+}
+
+// Launch geometry of v2: 4 waves per workgroup (so that the workgroup's waves are dealt to the CU's four
+// SIMDs), `lanes` active lanes per wave.
+constexpr uint32_t kV2Waves = 4;
+
+__global__ __launch_bounds__(256) void encode_kernel_v2(uint32_t n_sub, uint32_t lanes,
+                                                        const cabac_substream_desc *__restrict__ desc,
+                                                        const uint16_t *__restrict__ records, uint8_t *__restrict__ bytes,
+                                                        cabac_substream_result *__restrict__ results) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t sub = (blockIdx.x * kV2Waves + wave) * lanes + lane;
+  if (lane >= lanes || sub >= n_sub) return;
+  uint32_t *ctx = lds + (wave * lanes + lane) * kLaneStride;
+
+  const cabac_substream_desc d = desc[sub];
+  lane_ctx_init(ctx, d.qp, d.init_id & 3u);
+  EncState e;
+  e.low = 0;
+  e.range = 510;
+  e.buffered_byte = 0xff;
+  e.num_buffered = 0;
+  e.bits_left = 23;
+  LaneSink sink;
+  sink.dst = bytes + d.byte_offset;
+  sink.cap = d.byte_capacity;
+  sink.pos = 0;
+  sink.cur = 0;
+  uint32_t bad = 0;
+
+  const uint16_t *rec = records + d.rec_offset;
+  const uint32_t n = d.n_records;
+  uint32_t i = 0;
+  // head: single records until the pointer is 16-byte aligned
+  while (i < n && (reinterpret_cast<uintptr_t>(rec + i) & 15u)) lane_encode_record(rec[i++], ctx, e, sink, bad);
+  // body: 8 records per 16-byte load, next group prefetched while this one is coded
+  if (i + 8 <= n) {
+    uint4 nxt = *reinterpret_cast<const uint4 *>(rec + i);
+    while (i + 8 <= n) {
+      const uint4 cur = nxt;
+      if (i + 16 <= n) nxt = *reinterpret_cast<const uint4 *>(rec + i + 8);
+      uint32_t g0 = cur.x, g1 = cur.y, g2 = cur.z, g3 = cur.w;
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) {  // rolled on purpose: keeps the loop body small
+        lane_encode_record(g0 & 0xffffu, ctx, e, sink, bad);
+        g0 = __builtin_amdgcn_alignbit(g1, g0, 16);
+        g1 = __builtin_amdgcn_alignbit(g2, g1, 16);
+        g2 = __builtin_amdgcn_alignbit(g3, g2, 16);
+        g3 >>= 16;
+      }
+      i += 8;
+    }
+  }
+  while (i < n) lane_encode_record(rec[i++], ctx, e, sink, bad);
+
+  // finish(), arith_codec.cpp:339-357 (+ writeByteAlignment, bit_stream.cpp:152-155)
+  uint32_t held = 0, nheld = 0;
+  if (d.init_id & CABAC_SUB_FINISH) {
+    if (e.low >> (32 - e.bits_left)) {
+      lane_put(sink, e.buffered_byte + 1);
+      while (e.num_buffered > 1) {
+        lane_put(sink, 0x00);
+        e.num_buffered--;
+      }
+      e.low -= 1u << (32 - e.bits_left);
+    } else {
+      if (e.num_buffered > 0) lane_put(sink, e.buffered_byte);
+      while (e.num_buffered > 1) {
+        lane_put(sink, 0xff);
+        e.num_buffered--;
+      }
+    }
+    uint32_t nbf = (uint32_t)(24 - e.bits_left);
+    const uint32_t v = e.low >> 8;
+    while (nbf >= 8) {
+      lane_put(sink, (v >> (nbf - 8)) & 0xffu);
+      nbf -= 8;
+    }
+    nheld = nbf;
+    held = nbf ? ((v & ((1u << nbf) - 1u)) << (8 - nbf)) : 0;
+    if (d.init_id & CABAC_SUB_ALIGN_RBSP) {
+      held |= 1u << (7 - nheld);
+      lane_put(sink, held);
+      held = 0;
+      nheld = 0;
+    }
+  }
+  cabac_substream_result res;
+  res.n_bits = sink.pos * 8u + nheld;
+  if (nheld) lane_put(sink, held);
+  lane_sink_finish(sink);
+  res.flags = (sink.pos > sink.cap ? CABAC_RES_OVERFLOW : 0u) | (bad ? CABAC_RES_BAD_RECORD : 0u);
+  results[sub] = res;
+}
+
+// ---- decode, v2 --------------------------------------------------------------------------
+// The reference keeps a 16-bit `value` plus up to 8 prefetched bits and reads one byte each time
+// `bitsNeeded` crosses zero (arith_codec.cpp:257-260).  Bits below the compared 9 never influence a
+// decision before they are shifted up, so fetching them earlier is exactly equivalent; here the
+// window is 64 bits — value in [62:47] (bit 63 is headroom: decodeBinEP doubles value before it
+// compares, arith_codec.cpp:101), 9..47 valid look-ahead bits below — refilled 4 bytes at a time with
+// one rare branch.  S = total bits shifted gives the reference's counters back:
+// bytes read = 2 + S/8, bitsNeeded = S%8 - 8.
+struct LaneWindow {
+  const uint8_t *src;
+  uint32_t cap;
+  uint32_t hi, lo;   // the 64-bit window
+  int32_t look;      // valid look-ahead bits below bit 47
+  uint32_t rp;       // byte offset of the next refill
+  uint32_t nxt;      // prefetched dword at rp, still little-endian (swapped when consumed, so that
+                     // the load's latency hides behind ~36 bins instead of being waited for at once)
+};
+
+__device__ __forceinline__ uint32_t lane_load_le32(const uint8_t *src, uint32_t cap, uint32_t off) {
+  uint32_t w = 0;
+  if (off + 4u <= cap) {
+    w = *reinterpret_cast<const uint32_t *>(src + off);
+  } else {
+    for (uint32_t b = 0; b < 4; b++)
+      if (off + b < cap) w |= (uint32_t)src[off + b] << (8 * b);
+  }
+  return w;
+}
+
+__device__ __forceinline__ void window_shift(LaneWindow &w, int n) {
+  uint64_t v = ((uint64_t)w.hi << 32) | w.lo;
+  v <<= n;
+  w.hi = (uint32_t)(v >> 32);
+  w.lo = (uint32_t)v;
+  w.look -= n;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel_v2(uint32_t n_sub, uint32_t lanes,
+                                                        const cabac_substream_desc *__restrict__ desc,
+                                                        const uint16_t *__restrict__ records,
+                                                        const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
+                                                        cabac_substream_result *__restrict__ results) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t sub = (blockIdx.x * kV2Waves + wave) * lanes + lane;
+  if (lane >= lanes || sub >= n_sub) return;
+  uint32_t *ctx = lds + (wave * lanes + lane) * kLaneStride;
+
+  const cabac_substream_desc d = desc[sub];
+  lane_ctx_init(ctx, d.qp, d.init_id & 3u);
+
+  LaneWindow w;
+  w.src = bytes + d.byte_offset;
+  w.cap = d.byte_capacity;
+  {
+    const uint32_t first = __builtin_bswap32(lane_load_le32(w.src, w.cap, 0));  // start(): value = first two bytes (arith_codec.cpp:60-66)
+    w.hi = first >> 1;
+    w.lo = first << 31;
+  }
+  w.look = 16;
+  w.rp = 4;
+  w.nxt = lane_load_le32(w.src, w.cap, 4);
+  uint32_t range = 510;
+  uint32_t shifts = 0;  // S
+  uint32_t bad = 0;
+
+  const uint16_t *rec = records + d.rec_offset;
+  uint8_t *out = bins + d.rec_offset;
+  const uint32_t n = d.n_records;
+
+  auto decode_one = [&](uint32_t r) -> uint32_t {
+    if (w.look <= 15) {  // rare: every 32 consumed bits
+      const uint64_t add = (uint64_t)__builtin_bswap32(w.nxt) << (15 - w.look);
+      w.hi |= (uint32_t)(add >> 32);
+      w.lo |= (uint32_t)add;
+      w.look += 32;
+      w.rp += 4;
+      w.nxt = lane_load_le32(w.src, w.cap, w.rp);
+    }
+    const uint32_t id = r & CABAC_REC_ID_MASK;
+    const bool is_ctx = id < (uint32_t)kNumCtx;
+    const bool is_ep = id == CABAC_REC_EP;
+    const bool is_trm = id == CABAC_REC_TRM;
+    const uint32_t slot = is_ctx ? id : kDummySlot;
+    const uint32_t st = ctx[slot];
+    const uint32_t q8 = ctx2_q8(st);
+    const uint32_t mps = q8 >> 7;
+    const uint32_t k = is_ctx ? ctx2_k(q8) : 0u;
+    const uint32_t c = is_ctx ? 4u : (is_trm ? 2u : 0u);
+    const int ep = is_ep ? 1 : 0;
+    window_shift(w, ep);                                          // decodeBinEP doubles value first (:100-105)
+    const uint32_t t = (((range >> 5) * k) >> 1) + c;
+    const uint32_t rm = range - t;
+    const uint32_t sr = rm << 22;                                 // (range << 7) aligned to window bits [62:47]
+    const bool ge = w.hi >= sr;
+    // value >= scaledRange: LPS for a context bin (:262-273), bin 1 for bypass (:109-112) / terminate (:184-185)
+    const uint32_t bin = is_ctx ? (ge ? 1u - mps : mps) : (ge ? 1u : 0u);
+    const int nl = __builtin_clz(t | 1u) - 23;
+    const int nm = rm < 256u ? 1 : 0;
+    const bool renorm_lps = ge && is_ctx;
+    const int nsh = ge ? (is_ctx ? nl : 0) : nm;
+    w.hi -= (ge && !is_trm) ? sr : 0u;                            // terminate bin 1 leaves value untouched
+    range = (renorm_lps ? t : rm) << nsh;
+    window_shift(w, nsh);
+    shifts += (uint32_t)(nsh + ep);
+    if (id == CABAC_REC_ALIGN) range = 256;
+    bad |= (!is_ctx && id < CABAC_REC_ALIGN) ? 1u : 0u;
+    ctx[slot] = ctx2_update(st, bin);
+    return bin;
+  };
+
+  uint32_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(rec + i) & 15u)) {
+    out[i] = (uint8_t)decode_one(rec[i]);
+    i++;
+  }
+  if (i + 8 <= n) {
+    uint4 nxt = *reinterpret_cast<const uint4 *>(rec + i);
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(out + i) & 3u) == 0;
+    while (i + 8 <= n) {
+      const uint4 cur = nxt;
+      if (i + 16 <= n) nxt = *reinterpret_cast<const uint4 *>(rec + i + 8);
+      uint32_t g0 = cur.x, g1 = cur.y, g2 = cur.z, g3 = cur.w;
+      uint32_t lo = 0, hi = 0;  // 8 decoded bins, one byte each (bin k in byte k)
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) {
+        const uint32_t b = decode_one(g0 & 0xffffu);
+        g0 = __builtin_amdgcn_alignbit(g1, g0, 16);
+        g1 = __builtin_amdgcn_alignbit(g2, g1, 16);
+        g2 = __builtin_amdgcn_alignbit(g3, g2, 16);
+        g3 >>= 16;
+        lo = __builtin_amdgcn_alignbit(hi, lo, 8);   // shift the 64-bit byte queue right by one byte
+        hi = (hi >> 8) | (b << 24);
+      }
+      if (out_aligned) {
+        reinterpret_cast<uint32_t *>(out + i)[0] = lo;
+        reinterpret_cast<uint32_t *>(out + i)[1] = hi;
+      } else {
+        for (int k = 0; k < 4; k++) {
+          out[i + k] = (uint8_t)(lo >> (8 * k));
+          out[i + 4 + k] = (uint8_t)(hi >> (8 * k));
+        }
+      }
+      i += 8;
+    }
+  }
+  while (i < n) {
+    out[i] = (uint8_t)decode_one(rec[i]);
+    i++;
+  }
+
+  // the reference's counters from S (see the comment above LaneWindow)
+  const uint32_t bytes_read = 2u + (shifts >> 3);
+  const int32_t bits_needed = (int32_t)(shifts & 7u) - 8;
+  uint32_t flags = 0;
+  if (d.init_id & CABAC_SUB_FINISH) {
+    // BinDecoderBase::finish, arith_codec.cpp:68-73
+    uint32_t ok = 0;
+    if (bytes_read <= w.cap) {
+      const uint32_t last = w.src[bytes_read - 1];
+      ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
+    }
+    if (!ok) flags |= CABAC_RES_BAD_STOP;
+  }
+  if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;  // the reference throws "FIFO exceeded" at that read
+  if (bad) flags |= CABAC_RES_BAD_RECORD;
+  cabac_substream_result res;
+  res.n_bits = 8u * bytes_read + (uint32_t)bits_needed;
+  res.flags = flags;
+  results[sub] = res;
+}
+
+static size_t v2_lds_bytes(uint32_t lanes) { return (size_t)kV2Waves * lanes * kLaneStride * sizeof(uint32_t); }
+
+// lanes per wave for v2: smallest power of two that brings the grid down to <= ~1 wave per SIMD
+static uint32_t v2_lanes(uint32_t n_sub, int variant) {
+  uint32_t forced = (uint32_t)variant >> 8;
+  if (forced >= 1 && forced <= 8) return forced;
+  uint32_t l = 1;  // <= 8 lanes: 4 waves x 8 x 1 524 B of LDS stays under the 64 KB dynamic-LDS default
+  while (l < 8 && (n_sub + l - 1) / l > 1024u) l <<= 1;
+  return l;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from cabac_capi.cpp)
 hipError_t launch_ctx_init(hipStream_t st, uint32_t n_sub, const int32_t *qp, const uint32_t *init_id, uint32_t *state,
@@ -522,8 +925,15 @@ hipError_t launch_ctx_init(hipStream_t st, uint32_t n_sub, const int32_t *qp, co
 hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
-  (void)variant;
-  hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
+  const int kind = variant & 0xff;
+  if (kind != 2) {
+    hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
+  } else {
+    const uint32_t l = v2_lanes(n_sub, variant);
+    const uint32_t per_block = l * kV2Waves;
+    hipLaunchKernelGGL(encode_kernel_v2, dim3((n_sub + per_block - 1) / per_block), dim3(64 * kV2Waves), v2_lds_bytes(l),
+                       st, n_sub, l, desc, records, bytes, results);
+  }
   return hipGetLastError();
 }
 
@@ -531,8 +941,15 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
                          cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
-  (void)variant;
-  hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
+  const int kind = variant & 0xff;
+  if (kind != 2) {
+    hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
+  } else {
+    const uint32_t l = v2_lanes(n_sub, variant);
+    const uint32_t per_block = l * kV2Waves;
+    hipLaunchKernelGGL(decode_kernel_v2, dim3((n_sub + per_block - 1) / per_block), dim3(64 * kV2Waves), v2_lds_bytes(l),
+                       st, n_sub, l, desc, records, bytes, bins, results);
+  }
   return hipGetLastError();
 }
 

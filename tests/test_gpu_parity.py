@@ -15,9 +15,14 @@ from entropy_coding_amd.workload import CONFIGS, build_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def hip():
+# kernel variants: 0 = auto, 1 = v1 wave-serial, 2 | L << 8 = v2 lane-per-substream with L lanes per wave
+VARIANTS = {"auto": 0, "v1": 1, "v2_L1": 2 | (1 << 8), "v2_L4": 2 | (4 << 8), "v2_L8": 2 | (8 << 8)}
+
+
+@pytest.fixture(scope="module", params=list(VARIANTS))
+def hip(request):
     c = capi.CabacHip(0)   # raises without a GPU: there is no fallback
+    c.set_variant(VARIANTS[request.param], VARIANTS[request.param])
     yield c
     c.close()
 
