@@ -902,6 +902,331 @@ __global__ __launch_bounds__(256) void decode_kernel_v2(uint32_t n_sub, uint32_t
   results[sub] = res;
 }
 
+// ==========================================================================================
+// v3 "phased wave": one wavefront per substream like v1, restructured around the measured gfx950
+// cost model (tools/ubench_*.hip): every instruction of a wave costs ~4 issue cycles, a CU retires
+// about one scalar and one vector instruction per cycle in total, a VALU->SALU->VALU round trip is
+// ~55 cycles and a taken branch ~35.  With 16 waves per CU (C4) the kernel is bound by the number of
+// *scalar* instructions per bin, so everything that does not belong to the serial low/range chain is
+// moved onto the 64 lanes:
+//  encode: the context-state sequence of a 64-bin step does not depend on low/range at all (the bins
+//    are known), so it is resolved in parallel first: a 9-bit match-any groups the lanes by ctxId,
+//    each lane pulls the updated state from the previous lane of its group (ds_bpermute), one round
+//    per repeat of a context inside the step; every lane then derives its own LPS factor / LPS-or-MPS
+//    flag.  The scalar loop that remains is ~20 instructions per bin: range split, renormalisation,
+//    low update, byte output.
+//  decode: the bin is only known after the compare, so the update cannot run ahead; instead ALL lanes
+//    apply the decoded bin to their own copy of the state and the lanes holding that ctxId keep the
+//    result (vector work), and every lane re-derives its LPS factor, so the scalar chain only does the
+//    interval arithmetic.  Scalar and vector instruction counts per bin end up about equal.
+// Both use the packed context word of v2 (state0 | rate bits | state1 << 16).
+
+__device__ __forceinline__ uint64_t match_any9(uint32_t key) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 9; b++) {
+    const bool bit = (key >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+// info word of one bin for the scalar encode loop
+enum : uint32_t { kInfoLps = 0x100u, kInfoEp = 0x200u, kInfoEpOne = 0x400u, kInfoAlign = 0x800u };
+
+template <bool kAlign>
+__device__ __forceinline__ void enc3_step(uint32_t info, EncState &e, ByteSink &sink, int lane) {
+  int nb;
+  if (info & kInfoEp) {
+    // encodeBinEP, arith_codec.cpp:389-399
+    e.low = (e.low << 1) + ((info & kInfoEpOne) ? e.range : 0u);
+    nb = 1;
+  } else {
+    // encodeBin / encodeBinTrm with LPS width t (arith_codec.cpp:553-582, :460-478)
+    const uint32_t k = info & 31u, c = (info >> 5) & 7u;
+    const uint32_t t = (((e.range >> 5) * k) >> 1) + c;
+    const uint32_t rm = e.range - t;
+    if (info & kInfoLps) {
+      nb = __builtin_clz(t) - 23;
+      e.low = (e.low + rm) << nb;
+      e.range = t << nb;
+    } else {
+      nb = (int)((rm >> 8) ^ 1u);
+      e.low <<= nb;
+      e.range = rm << nb;
+    }
+    if (kAlign && (info & kInfoAlign)) e.range = 256;
+  }
+  e.bits_left -= nb;
+  if (e.bits_left < 12) enc_write_out(e, sink, lane);
+}
+
+__global__ __launch_bounds__(64) void encode_kernel_v3(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                       const uint16_t *__restrict__ records, uint8_t *__restrict__ bytes,
+                                                       cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx[kNumCtx + 5];
+  const int lane = threadIdx.x;
+  const uint32_t sub = blockIdx.x;
+  if (sub >= n_sub) return;
+
+  const cabac_substream_desc d = desc[sub];
+  const uint32_t n = d.n_records;
+  const uint16_t *rec = records + d.rec_offset;
+  {
+    const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
+    const uint32_t iid = d.init_id & 3u;
+    for (int k = lane; k < kNumCtx; k += 64)
+      ctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+  }
+  __syncthreads();
+
+  EncState e;
+  e.low = 0;
+  e.range = 510;
+  e.buffered_byte = 0xff;
+  e.num_buffered = 0;
+  e.bits_left = 23;
+  ByteSink sink;
+  sink.dst = bytes + d.byte_offset;
+  sink.cap = d.byte_capacity;
+  sink.pos = 0;
+  sink.cur = 0;
+  sink.window = 0;
+  uint32_t bad = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+  uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
+    const uint32_t r = next_rec;
+    {
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
+    const bool active = (uint32_t)lane < cnt;
+    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+    const uint32_t bin = (r >> 15) & 1u;
+    const bool is_ctx = id < (uint32_t)kNumCtx;
+    const bool is_ep = active && id == CABAC_REC_EP;
+    const bool is_trm = active && id == CABAC_REC_TRM;
+    const bool is_align = active && id == CABAC_REC_ALIGN;
+    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+
+    // ---- phase A: the context state each bin sees (parallel over the 64 bins) ----------------
+    const uint64_t same = match_any9(id);
+    const uint64_t before = same & lt_mask;
+    const uint32_t prev = 63u - (uint32_t)__builtin_clzll(before | 1ull);
+    const bool is_last = (same & ~lt_mask & ~(1ull << lane)) == 0;
+    uint32_t st = is_ctx ? ctx[id] : 0u;
+    bool pending = is_ctx && before != 0;
+    for (;;) {
+      const uint64_t pend = __ballot(pending);
+      if (pend == 0) break;
+      const uint32_t post = ctx2_update(st, bin);
+      const uint32_t pulled = __shfl(post, (int)prev);
+      if (pending && !((pend >> prev) & 1ull)) {  // the previous bin of this context is settled
+        st = pulled;
+        pending = false;
+      }
+    }
+    if (is_ctx && is_last) ctx[id] = ctx2_update(st, bin);
+    const uint32_t q8 = ctx2_q8(st);
+    const uint32_t mps = q8 >> 7;
+    uint32_t info = 0;
+    if (is_ctx) info = ctx2_k(q8) | (4u << 5) | ((bin ^ mps) ? kInfoLps : 0u);
+    if (is_trm) info = (2u << 5) | (bin ? kInfoLps : 0u);
+    if (is_ep) info = kInfoEp | (bin ? kInfoEpOne : 0u);
+    if (is_align) info = kInfoAlign;
+    const bool any_align = __ballot(is_align) != 0;
+
+    // ---- phase B: the serial low / range chain (wave-uniform) -------------------------------
+    if (!any_align && cnt == 64u) {
+#pragma unroll 8
+      for (uint32_t i = 0; i < 64u; i++) enc3_step<false>(__builtin_amdgcn_readlane(info, i), e, sink, lane);
+    } else {
+      for (uint32_t i = 0; i < cnt; i++) enc3_step<true>(__builtin_amdgcn_readlane(info, i), e, sink, lane);
+    }
+  }
+
+  const uint32_t n_bits = enc_finish(e, sink, (d.init_id & CABAC_SUB_FINISH) != 0,
+                                     (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, lane);
+  const uint64_t any_bad = __ballot(bad != 0);
+  if (lane == 0) {
+    cabac_substream_result res;
+    res.n_bits = n_bits;
+    res.flags = (sink.pos > sink.cap ? CABAC_RES_OVERFLOW : 0u) | (any_bad ? CABAC_RES_BAD_RECORD : 0u);
+    results[sub] = res;
+  }
+}
+
+// ---- decode, v3 ----------------------------------------------------------------------------
+enum : uint32_t { kDecEp = 0x8u, kDecCtx = 0x10u, kDecAlign = 0x20u };  // bits 2..0 = c, bits 16.. = ctxId
+
+__device__ __forceinline__ uint32_t dec3_window_load(const uint8_t *src, uint32_t cap, uint32_t off) {
+  // one big-endian dword per lane: lane l holds stream bytes [off + 4l, +4), first byte in bits 31..24
+  return __builtin_bswap32(lane_load_le32(src, cap, off));
+}
+
+__global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                       const uint16_t *__restrict__ records,
+                                                       const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
+                                                       cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx[kNumCtx + 5];
+  const int lane = threadIdx.x;
+  const uint32_t sub = blockIdx.x;
+  if (sub >= n_sub) return;
+
+  const cabac_substream_desc d = desc[sub];
+  const uint32_t n = d.n_records;
+  const uint16_t *rec = records + d.rec_offset;
+  uint8_t *out = bins + d.rec_offset;
+  {
+    const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
+    const uint32_t iid = d.init_id & 3u;
+    for (int k = lane; k < kNumCtx; k += 64)
+      ctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+  }
+  __syncthreads();
+
+  const uint8_t *src = bytes + d.byte_offset;
+  const uint32_t cap = d.byte_capacity;
+  // input: 256-byte windows, 4 bytes per lane, the next window prefetched
+  uint32_t win_cur = dec3_window_load(src, cap, 4u * (uint32_t)lane);
+  uint32_t win_nxt = dec3_window_load(src, cap, 256u + 4u * (uint32_t)lane);
+  // 64-bit decode window as in v2: value in [62:47], `look` valid bits below (scalar)
+  uint32_t hi, lo;
+  {
+    const uint32_t first = __builtin_amdgcn_readlane(win_cur, 0);
+    hi = first >> 1;
+    lo = first << 31;
+  }
+  int32_t look = 16;
+  uint32_t rp = 4;  // byte offset of the next refill dword
+  uint32_t range = 510, shifts = 0, bad = 0;
+
+  uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
+    const uint32_t r = next_rec;
+    {
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
+    const bool active = (uint32_t)lane < cnt;
+    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+    const bool is_ctx = id < (uint32_t)kNumCtx;
+    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+    uint32_t st_v = is_ctx ? ctx[id] : 0u;
+    const uint32_t key_v = is_ctx ? id : 0xffffu;
+    // per-lane constants of the update (the rates of a context never change)
+    const uint32_t r0_v = (st_v & 3u) + 2u, r1_v = ((st_v >> 2) & 7u) + 5u;
+    const uint32_t a_v = ((0x7fffu >> r0_v) & kMask0) | (((0x7fffu >> r1_v) & kMask1) << 16);
+    uint32_t kq_v;  // k | mps << 5 of this lane's context as it stands
+    {
+      const uint32_t q8 = ctx2_q8(st_v);
+      kq_v = is_ctx ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+    }
+    uint32_t info_v = 0;
+    if (is_ctx) info_v = 4u | kDecCtx | (id << 16);
+    else if (active && id == CABAC_REC_TRM) info_v = 2u;
+    else if (active && id == CABAC_REC_EP) info_v = kDecEp;
+    else if (active && id == CABAC_REC_ALIGN) info_v = kDecAlign;
+    uint64_t bin_mask = 0;
+
+    for (uint32_t i = 0; i < cnt; i++) {
+      if (look <= 15) {  // refill 32 bits (every ~36 bins)
+        const uint32_t w = __builtin_amdgcn_readlane(win_cur, (rp >> 2) & 63u);
+        const uint64_t add = (uint64_t)w << (15 - look);
+        hi |= (uint32_t)(add >> 32);
+        lo |= (uint32_t)add;
+        look += 32;
+        rp += 4;
+        if ((rp & 255u) == 0u) {
+          win_cur = win_nxt;
+          win_nxt = dec3_window_load(src, cap, rp + 256u + 4u * (uint32_t)lane);
+        }
+      }
+      const uint32_t info = __builtin_amdgcn_readlane(info_v, i);
+      uint32_t bin;
+      if (info & kDecEp) {
+        // decodeBinEP, arith_codec.cpp:100-114
+        hi = (hi << 1) | (lo >> 31);
+        lo <<= 1;
+        const uint32_t sr = range << 22;
+        bin = hi >= sr ? 1u : 0u;
+        hi -= bin ? sr : 0u;
+        shifts += 1;
+        look -= 1;
+      } else {
+        const uint32_t kq = __builtin_amdgcn_readlane(kq_v, i);
+        const uint32_t k = kq & 31u, mps = kq >> 5, c = info & 7u;
+        const uint32_t t = (((range >> 5) * k) >> 1) + c;
+        const uint32_t rm = range - t;
+        const uint32_t sr = rm << 22;
+        int nb;
+        if (hi >= sr) {
+          if (info & kDecCtx) {  // LPS path, arith_codec.cpp:262-273
+            nb = __builtin_clz(t) - 23;
+            hi -= sr;
+            range = t << nb;
+            bin = 1u - mps;
+          } else {  // terminate bin 1, :184-185
+            nb = 0;
+            range = rm;
+            bin = 1;
+          }
+        } else {  // MPS path :250-261 / terminate bin 0 :186-195
+          nb = (int)((rm >> 8) ^ 1u);
+          range = rm << nb;
+          bin = mps;  // mps == 0 for non-context records
+        }
+        {
+          const uint64_t v = (((uint64_t)hi << 32) | lo) << nb;
+          hi = (uint32_t)(v >> 32);
+          lo = (uint32_t)v;
+        }
+        shifts += (uint32_t)nb;
+        look -= nb;
+        if (info & kDecCtx) {
+          // vector side: every lane applies the bin to its own copy; lanes of this context keep it
+          const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
+          const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
+          const uint32_t upd = st_v - dlt + (bin ? a_v : 0u);
+          st_v = (key_v == (info >> 16)) ? upd : st_v;
+          const uint32_t q8 = ctx2_q8(st_v);
+          kq_v = is_ctx ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+        }
+        if (info & kDecAlign) range = 256;
+      }
+      bin_mask |= (uint64_t)bin << i;
+    }
+    if (is_ctx) ctx[id] = st_v;
+    if (active) out[base + lane] = (uint8_t)((bin_mask >> lane) & 1u);
+  }
+
+  const uint32_t bytes_read = 2u + (shifts >> 3);
+  const int32_t bits_needed = (int32_t)(shifts & 7u) - 8;
+  uint32_t flags = 0;
+  if (d.init_id & CABAC_SUB_FINISH) {
+    uint32_t ok = 0;
+    if (bytes_read <= cap) {
+      const uint32_t last = src[bytes_read - 1];
+      ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
+    }
+    if (!ok) flags |= CABAC_RES_BAD_STOP;
+  }
+  if (bytes_read > cap) flags |= CABAC_RES_UNDERRUN;
+  const uint64_t any_bad = __ballot(bad != 0);
+  if (any_bad) flags |= CABAC_RES_BAD_RECORD;
+  if (lane == 0) {
+    cabac_substream_result res;
+    res.n_bits = 8u * bytes_read + (uint32_t)bits_needed;
+    res.flags = flags;
+    results[sub] = res;
+  }
+}
+
 static size_t v2_lds_bytes(uint32_t lanes) { return (size_t)kV2Waves * lanes * kLaneStride * sizeof(uint32_t); }
 
 // lanes per wave for v2: smallest power of two that brings the grid down to <= ~1 wave per SIMD
@@ -926,8 +1251,10 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  if (kind != 2) {
+  if (kind == 1) {
     hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
+  } else if (kind != 2) {
+    hipLaunchKernelGGL(encode_kernel_v3, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
   } else {
     const uint32_t l = v2_lanes(n_sub, variant);
     const uint32_t per_block = l * kV2Waves;
@@ -942,8 +1269,10 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  if (kind != 2) {
+  if (kind == 1) {
     hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
+  } else if (kind != 2) {
+    hipLaunchKernelGGL(decode_kernel_v3, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
   } else {
     const uint32_t l = v2_lanes(n_sub, variant);
     const uint32_t per_block = l * kV2Waves;
