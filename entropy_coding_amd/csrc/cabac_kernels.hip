@@ -29,75 +29,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "cabac_ctx_tables.h"
+#include "cabac_device.h"
 #include "cabac_hip.h"
 #include "cabac_kernels.h"
 
 namespace cabac {
-
-__constant__ uint8_t c_init_tables[CABAC_CTX_TABLE_ROWS * CABAC_CTX_TABLE_COLS] = {CABAC_CTX_INIT_TABLE_VALUES};
-
-constexpr int kNumCtx = CABAC_NUM_CONTEXTS;
-constexpr uint32_t kMask0 = 0x7FE0u;  // contexts.hpp:18-19
-constexpr uint32_t kMask1 = 0x7FFEu;  // contexts.hpp:20-21
-
-// LDS context entry: x = state0 | state1 << 16 (the two 15-bit estimators exactly as the
-// reference keeps them), y = rate0 | (16 + rate1) << 8 | add1 << 16 is not needed: y = rates.
-struct CtxEntry {
-  uint32_t state;  // s0 | s1 << 16
-  uint32_t rates;  // r0 | r1 << 8
-};
-
-__device__ __forceinline__ uint32_t ctx_init_state(int qp, uint32_t init_value) {
-  // BinProbModel_Std::init, contexts.cpp:893-901
-  int slope = (int)(init_value >> 3) - 4;
-  int offset = (int)(init_value & 7) * 18 + 1;
-  int st = ((slope * (qp - 16)) >> 1) + offset;
-  st = st < 1 ? 1 : (st > 127 ? 127 : st);
-  uint32_t p1 = (uint32_t)st << 8;
-  return (p1 & kMask0) | ((p1 & kMask1) << 16);
-}
-
-__device__ __forceinline__ uint32_t ctx_init_rates(uint32_t w) {
-  // setLog2WindowSize, contexts.cpp:915-920
-  uint32_t r0 = 2 + ((w >> 2) & 3);
-  uint32_t r1 = 3 + r0 + (w & 3);
-  return r0 | (r1 << 8);
-}
-
-__device__ __forceinline__ void ctx_store_init(CtxEntry *ctx, int qp, uint32_t init_id, int lane) {
-  qp = qp < 0 ? 0 : (qp > 63 ? 63 : qp);  // CtxStore::init clips, contexts.cpp:1010
-  for (int k = lane; k < kNumCtx; k += 64) {
-    CtxEntry e;
-    e.state = ctx_init_state(qp, c_init_tables[init_id * kNumCtx + k]);
-    e.rates = ctx_init_rates(c_init_tables[3 * kNumCtx + k]);
-    ctx[k] = e;
-  }
-}
-
-// state() >> folded LPS multiplier, contexts.cpp:939-950.  All scalar.
-__device__ __forceinline__ uint32_t state8(uint32_t st) { return (((st & 0xffffu) + (st >> 16)) >> 8) & 0xffu; }
-
-__device__ __forceinline__ uint32_t lps_of(uint32_t q8, uint32_t range) {
-  uint32_t q = (q8 & 0x80u) ? (q8 ^ 0xffu) : q8;
-  return (((q >> 2) * (range >> 5)) >> 1) + 4;
-}
-
-// getRenormBitsLPS: m_RenormTable_32[LPS >> 3] == 8 - floor(log2(LPS)) for LPS in 4..255
-__device__ __forceinline__ int renorm_bits_lps(uint32_t lps) { return __builtin_clz(lps) - 23; }
-
-// update(bin), contexts.cpp:903-913, on the packed word
-__device__ __forceinline__ uint32_t ctx_update(uint32_t st, uint32_t rates, uint32_t bin) {
-  uint32_t r0 = rates & 0xffu, r1 = rates >> 8;
-  uint32_t s0 = st & 0xffffu, s1 = st >> 16;
-  s0 -= (s0 >> r0) & kMask0;
-  s1 -= (s1 >> r1) & kMask1;
-  if (bin) {
-    s0 += (0x7fffu >> r0) & kMask0;
-    s1 += (0x7fffu >> r1) & kMask1;
-  }
-  return s0 | (s1 << 16);
-}
 
 // ------------------------------------------------------------------------------------------
 // ctx-init only kernel (parity tests of a2/a3 in SURVEY.md §8a)
@@ -526,33 +462,6 @@ __global__ __launch_bounds__(64) void decode_kernel_v1(uint32_t n_sub, const cab
 // word = state0[14:5] | rate bits[4:0] | state1 << 16, rate bits [1:0] = rate0 - 2, [4:2] = rate1 - 5
 // (rate1 <= 9 is CHECKed by the reference, contexts.cpp:919).  The rate bits ride along untouched
 // because every update term is masked.
-constexpr int kLaneStride = 381;
-constexpr uint32_t kDummySlot = 379;
-
-__device__ __forceinline__ uint32_t ctx2_init(int qp, uint32_t init_value, uint32_t w) {
-  uint32_t st = ctx_init_state(qp, init_value);
-  uint32_t r = ctx_init_rates(w);
-  uint32_t r0 = r & 0xffu, r1 = r >> 8;
-  return st | (r0 - 2u) | ((r1 - 5u) << 2);
-}
-
-// q8 = state() of the packed word (contexts.cpp:939-941)
-__device__ __forceinline__ uint32_t ctx2_q8(uint32_t st) { return (((st & kMask0) + (st >> 16)) >> 8) & 0xffu; }
-
-// (q folded to 0..127) >> 2, contexts.cpp:945-949
-__device__ __forceinline__ uint32_t ctx2_k(uint32_t q8) {
-  const uint32_t x = (uint32_t)((int32_t)(q8 << 24) >> 31);  // 0 or ~0 from bit 7
-  return ((q8 ^ x) >> 2) & 31u;
-}
-
-__device__ __forceinline__ uint32_t ctx2_update(uint32_t st, uint32_t bin) {
-  const uint32_t r0 = (st & 3u) + 2u, r1 = ((st >> 2) & 7u) + 5u;
-  const uint32_t s0 = st & kMask0, s1 = st >> 16;
-  const uint32_t d = ((s0 >> r0) & kMask0) | (((s1 >> r1) & kMask1) << 16);
-  const uint32_t a = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
-  return st - d + (bin ? a : 0u);  // halves never borrow/carry into each other (15-bit estimators)
-}
-
 __device__ __forceinline__ void lane_ctx_init(uint32_t *ctx, int qp_in, uint32_t iid) {
   const int qp = qp_in < 0 ? 0 : (qp_in > 63 ? 63 : qp_in);
   for (int k = 0; k < kNumCtx; k++)
@@ -747,17 +656,6 @@ struct LaneWindow {
   uint32_t nxt;      // prefetched dword at rp, still little-endian (swapped when consumed, so that
                      // the load's latency hides behind ~36 bins instead of being waited for at once)
 };
-
-__device__ __forceinline__ uint32_t lane_load_le32(const uint8_t *src, uint32_t cap, uint32_t off) {
-  uint32_t w = 0;
-  if (off + 4u <= cap) {
-    w = *reinterpret_cast<const uint32_t *>(src + off);
-  } else {
-    for (uint32_t b = 0; b < 4; b++)
-      if (off + b < cap) w |= (uint32_t)src[off + b] << (8 * b);
-  }
-  return w;
-}
 
 __device__ __forceinline__ void window_shift(LaneWindow &w, int n) {
   uint64_t v = ((uint64_t)w.hi << 32) | w.lo;
@@ -1132,7 +1030,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
     else if (active && id == CABAC_REC_TRM) info_v = 2u;
     else if (active && id == CABAC_REC_EP) info_v = kDecEp;
     else if (active && id == CABAC_REC_ALIGN) info_v = kDecAlign;
-    uint64_t bin_mask = 0;
+    uint32_t my_bin = 0;
 
     for (uint32_t i = 0; i < cnt; i++) {
       if (look <= 15) {  // refill 32 bits (every ~36 bins)
@@ -1151,11 +1049,14 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
       uint32_t bin;
       if (info & kDecEp) {
         // decodeBinEP, arith_codec.cpp:100-114
-        hi = (hi << 1) | (lo >> 31);
-        lo <<= 1;
+        {
+          const uint64_t v = (((uint64_t)hi << 32) | lo) << 1;
+          hi = (uint32_t)(v >> 32);
+          lo = (uint32_t)v;
+        }
         const uint32_t sr = range << 22;
         bin = hi >= sr ? 1u : 0u;
-        hi -= bin ? sr : 0u;
+        hi -= hi >= sr ? sr : 0u;
         shifts += 1;
         look -= 1;
       } else {
@@ -1199,10 +1100,10 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
         }
         if (info & kDecAlign) range = 256;
       }
-      bin_mask |= (uint64_t)bin << i;
+      my_bin = ((uint32_t)lane == i) ? bin : my_bin;  // vector side keeps lane i's bin (no scalar mask upkeep)
     }
     if (is_ctx) ctx[id] = st_v;
-    if (active) out[base + lane] = (uint8_t)((bin_mask >> lane) & 1u);
+    if (active) out[base + lane] = (uint8_t)my_bin;
   }
 
   const uint32_t bytes_read = 2u + (shifts >> 3);
@@ -1251,6 +1152,9 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
+  // auto: with >= 2 048 substreams the quad kernels fill the chip better (4 bins per instruction);
+  // below that one wave per substream (v3) keeps more SIMDs busy
+  if (kind == 4 || (kind == 0 && n_sub >= 2048u)) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
   if (kind == 1) {
     hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
   } else if (kind != 2) {
@@ -1269,6 +1173,7 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
+  if (kind == 4 || (kind == 0 && n_sub >= 2048u)) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results);
   if (kind == 1) {
     hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
   } else if (kind != 2) {

@@ -1,0 +1,442 @@
+// v4 "quad" kernels: FOUR substreams per wavefront, 16 lanes each, serial chain on the VECTOR pipe.
+//
+// Measured cost model of gfx950 (tools/ubench_issue.hip, tools/ubench_cross.hip): a wave issues one
+// instruction per ~4-5 cycles whether scalar or vector; a CU retires ~1 scalar + ~1 vector
+// instruction per cycle in total.  With one substream per wave (v1, v3) every instruction of the
+// serial low/range chain advances ONE bin, so a 4 096-substream batch is bound by instructions per
+// bin.  Here the four 16-lane rows of a wave carry four different substreams and the chain is written
+// with per-lane (row-uniform) vector arithmetic, so one instruction advances FOUR bins; the record of
+// step i is delivered to its row with a DPP row broadcast (v_mov_b32_dpp row_newbcast:i — one
+// instruction, no LDS, no scalar round trip).  Everything row-divergent is select-based; the only
+// branches are the rare ones (16-bit output flush, input refill).
+//
+//  encode: per 16-bin step  (a) the context states the 16 bins of each row see are resolved in
+//          parallel exactly as in v3 (match-any on ctxId|row, ds_bpermute rounds);  (b) 16 unrolled
+//          chain steps of ~27 vector instructions for the 4 rows together.
+//          Byte output: `low` is kept as the exact code value and 16 bits are peeled off whenever 16
+//          have accumulated; the delayed carry of arith_codec.cpp:524-546 (buffered byte + count of
+//          outstanding 0xFF) is the same algorithm in base 2^16 (buffered unit + count of outstanding
+//          0xFFFF).  The emitted stream is the identical number: the top S+1 bits of low >> 8 with
+//          carries resolved (S = bits shifted), which is what finish() (:339-357) leaves.
+//  decode: the 64-bit look-ahead window of v2 per row; after each bin every lane applies it to its own
+//          copy of the context state and the lanes of that row holding the same ctxId keep it.
+//
+// Layout: row r of wave w codes substream 4w + r.  Rows whose substreams are shorter idle at the end,
+// so batches should group substreams of similar length (cabac_hip.h: order is the caller's).
+#include "cabac_device.h"
+#include "cabac_kernels.h"
+
+namespace cabac {
+
+constexpr uint32_t kQuadSubs = 4;        // substreams (rows) per wave
+constexpr uint32_t kQuadCtxStride = 380; // LDS words per row context store (379 + pad)
+
+template <int I>
+__device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
+  // lane I of every 16-lane row -> all lanes of that row (DPP_ROW_NEWBCAST0 = 0x150, gfx90a+)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, false);
+}
+
+template <int BITS>
+__device__ __forceinline__ uint64_t match_any_bits(uint32_t key) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < BITS; b++) {
+    const bool bit = (key >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode
+enum : uint32_t { kQLps = 0x200u, kQEp = 0x400u, kQEpOne = 0x800u, kQAlign = 0x1000u };  // bits 4..0 k, 8..5 2c
+
+struct QuadEnc {       // row-uniform values
+  uint32_t low;        // exact code value: 9 + pend (+1 carry) bits
+  uint32_t range;
+  int32_t pend;        // bits shifted since the last 16-bit unit was peeled off (< 16 between steps)
+  uint32_t buf;        // buffered unit
+  int32_t nbuf;        // buffered unit + outstanding 0xFFFF units
+  uint32_t pos;        // bytes stored so far
+  uint8_t *dst;
+  uint32_t cap;
+};
+
+__device__ __forceinline__ void quad_put_byte(QuadEnc &e, uint32_t byte, bool writer) {
+  if (writer && e.pos < e.cap) e.dst[e.pos] = (uint8_t)byte;
+  e.pos += 1;
+}
+
+__device__ __forceinline__ void quad_put16(QuadEnc &e, uint32_t unit, bool writer) {
+  // big-endian 16-bit unit at byte offset pos (pos is even until finish)
+  if (writer) {
+    if (e.pos + 2u <= e.cap) {
+      *reinterpret_cast<uint16_t *>(e.dst + e.pos) = (uint16_t)(((unit & 0xffu) << 8) | ((unit >> 8) & 0xffu));
+    } else if (e.pos < e.cap) {
+      e.dst[e.pos] = (uint8_t)(unit >> 8);
+    }
+  }
+  e.pos += 2;
+}
+
+// peel 16 bits off the top of low; delayed carry as writeOut (arith_codec.cpp:524-546) in base 2^16
+__device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
+  const uint32_t sh = (uint32_t)(9 + e.pend - 16);
+  const uint32_t lead = e.low >> sh;  // carry + 16 bits
+  e.low &= (1u << sh) - 1u;
+  e.pend -= 16;
+  const bool is_ff = lead == 0xffffu;
+  const bool emit = !is_ff && e.nbuf > 0;
+  const uint32_t carry = lead >> 16;
+  const uint32_t first = e.buf + carry;
+  const int32_t fill_n = e.nbuf - 1;
+  e.buf = is_ff ? e.buf : (lead & 0xffffu);
+  e.nbuf = is_ff ? e.nbuf + 1 : 1;
+  if (emit) {
+    quad_put16(e, first, writer);
+    for (int32_t k = 0; k < fill_n; k++) quad_put16(e, 0xffffu + carry, writer);
+  }
+}
+
+template <int I, bool kAlign>
+__device__ __forceinline__ void quad_enc_step(uint32_t info_v, QuadEnc &e, bool writer) {
+  const uint32_t info = row_bcast<I>(info_v);
+  const uint32_t k = info & 31u, c2 = (info >> 5) & 15u;
+  const uint32_t t = ((((e.range >> 5) & 15u) * k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+  const uint32_t rm = e.range - t;
+  const bool lps = (info & kQLps) != 0;
+  const int nl = __builtin_clz(t | 1u) - 23;  // getRenormBitsLPS (contexts.cpp:952-954); unused when t == 0
+  const int nm = rm < 256u ? 1 : 0;
+  const int nb = lps ? nl : nm;
+  e.low = (e.low + (lps ? rm : 0u)) << nb;
+  e.range = (lps ? t : rm) << nb;
+  const uint32_t ep = (info >> 10) & 1u;
+  e.low = (e.low << ep) + ((info & kQEpOne) ? e.range : 0u);  // encodeBinEP (arith_codec.cpp:389-399)
+  if (kAlign && (info & kQAlign)) e.range = 256;
+  e.pend += nb + (int)ep;
+  if (e.pend >= 16) quad_flush16(e, writer);
+}
+
+template <bool kAlign>
+__device__ __forceinline__ void quad_enc_steps(uint32_t info_v, QuadEnc &e, bool writer) {
+  quad_enc_step<0, kAlign>(info_v, e, writer);
+  quad_enc_step<1, kAlign>(info_v, e, writer);
+  quad_enc_step<2, kAlign>(info_v, e, writer);
+  quad_enc_step<3, kAlign>(info_v, e, writer);
+  quad_enc_step<4, kAlign>(info_v, e, writer);
+  quad_enc_step<5, kAlign>(info_v, e, writer);
+  quad_enc_step<6, kAlign>(info_v, e, writer);
+  quad_enc_step<7, kAlign>(info_v, e, writer);
+  quad_enc_step<8, kAlign>(info_v, e, writer);
+  quad_enc_step<9, kAlign>(info_v, e, writer);
+  quad_enc_step<10, kAlign>(info_v, e, writer);
+  quad_enc_step<11, kAlign>(info_v, e, writer);
+  quad_enc_step<12, kAlign>(info_v, e, writer);
+  quad_enc_step<13, kAlign>(info_v, e, writer);
+  quad_enc_step<14, kAlign>(info_v, e, writer);
+  quad_enc_step<15, kAlign>(info_v, e, writer);
+}
+
+__global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                       const uint16_t *__restrict__ records, uint8_t *__restrict__ bytes,
+                                                       cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx[kQuadSubs * kQuadCtxStride];
+  const uint32_t lane = threadIdx.x, row = lane >> 4, j = lane & 15u;
+  const uint32_t sub = blockIdx.x * kQuadSubs + row;
+  const bool live = sub < n_sub;  // rows beyond the batch idle with n = 0
+  const cabac_substream_desc d = desc[live ? sub : 0];
+  const uint32_t n = live ? d.n_records : 0u;
+  const uint16_t *rec = records + d.rec_offset;
+  uint32_t *rctx = ctx + row * kQuadCtxStride;
+  {
+    const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
+    const uint32_t iid = d.init_id & 3u;
+    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16)
+      rctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+  }
+  __syncthreads();
+
+  QuadEnc e;
+  e.low = 0;
+  e.range = 510;  // start(), arith_codec.cpp:329-337
+  e.pend = 0;
+  e.buf = 0;
+  e.nbuf = 0;
+  e.pos = 0;
+  e.dst = bytes + d.byte_offset;
+  e.cap = live ? d.byte_capacity : 0u;
+  const bool writer = live && j == 0;
+  uint32_t bad = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+  uint32_t next_rec = j < n ? rec[j] : 0;
+  for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
+    const uint32_t r = next_rec;
+    {
+      const uint32_t nxt = base + 16u + j;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
+    const bool active = base + j < n;
+    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+    const uint32_t bin = (r >> 15) & 1u;
+    const bool is_ctx = id < (uint32_t)kNumCtx;
+    const bool is_ep = active && id == CABAC_REC_EP;
+    const bool is_trm = active && id == CABAC_REC_TRM;
+    const bool is_align = active && id == CABAC_REC_ALIGN;
+    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+
+    // (a) the context state each bin sees — parallel over the 4 x 16 bins (see v3)
+    const uint64_t same = match_any_bits<11>(id | (row << 9));
+    const uint64_t before = same & lt_mask;
+    const uint32_t prev = 63u - (uint32_t)__builtin_clzll(before | 1ull);
+    const bool is_last = (same & ~lt_mask & ~(1ull << lane)) == 0;
+    uint32_t st = is_ctx ? rctx[id] : 0u;
+    bool pending = is_ctx && before != 0;
+    for (;;) {
+      const uint64_t pend = __ballot(pending);
+      if (pend == 0) break;
+      const uint32_t post = ctx2_update(st, bin);
+      const uint32_t pulled = __shfl(post, (int)prev);
+      if (pending && !((pend >> prev) & 1ull)) {
+        st = pulled;
+        pending = false;
+      }
+    }
+    if (is_ctx && is_last) rctx[id] = ctx2_update(st, bin);
+    const uint32_t q8 = ctx2_q8(st);
+    const uint32_t mps = q8 >> 7;
+    uint32_t info = 0;  // inactive lanes: t = 0, no shift — a no-op step
+    if (is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) ? kQLps : 0u);
+    if (is_trm) info = (4u << 5) | (bin ? kQLps : 0u);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
+    if (is_ep) info = kQEp | (bin ? kQEpOne : 0u);
+    if (is_align) info = kQAlign;
+
+    // (b) the serial chain, 4 rows at once
+    if (__ballot(is_align) == 0) quad_enc_steps<false>(info, e, writer);
+    else quad_enc_steps<true>(info, e, writer);
+  }
+
+  // finish(), arith_codec.cpp:339-357, on the exact code value
+  uint32_t n_bits = 0;
+  if (live) {
+    const uint32_t total = (uint32_t)(9 + e.pend);
+    if ((e.low >> total) & 1u) {
+      quad_put16(e, e.buf + 1u, writer);
+      for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0x0000u, writer);
+      e.low -= 1u << total;
+    } else {
+      if (e.nbuf > 0) quad_put16(e, e.buf, writer);
+      for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0xffffu, writer);
+    }
+    uint32_t nb = (uint32_t)(e.pend + 1);  // write(low >> 8, 24 - bitsLeft)
+    const uint32_t v = e.low >> 8;
+    while (nb >= 8) {
+      quad_put_byte(e, (v >> (nb - 8)) & 0xffu, writer);
+      nb -= 8;
+    }
+    uint32_t held = nb ? ((v & ((1u << nb) - 1u)) << (8 - nb)) : 0u;
+    if (d.init_id & CABAC_SUB_ALIGN_RBSP) {  // writeByteAlignment, bit_stream.cpp:152-155
+      held |= 1u << (7 - nb);
+      quad_put_byte(e, held, writer);
+      held = 0;
+      nb = 0;
+    }
+    n_bits = e.pos * 8u + nb;
+    if (nb) quad_put_byte(e, held, writer);
+  }
+  // row-wide OR of the bad-record flag
+  const uint64_t bad_mask = __ballot(bad != 0);
+  const bool row_bad = ((bad_mask >> (row * 16u)) & 0xffffull) != 0;
+  if (writer) {
+    cabac_substream_result res;
+    res.n_bits = n_bits;
+    res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (row_bad ? CABAC_RES_BAD_RECORD : 0u);
+    results[sub] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode
+enum : uint32_t { kQDecEp = 0x10u, kQDecCtx = 0x20u, kQDecTrm = 0x40u, kQDecAlign = 0x80u, kQDecNop = 0x100u };  // bits 3..0 = 2c, 27..16 = key
+
+struct QuadDec {   // row-uniform values
+  uint32_t hi, lo;   // 64-bit window: value in [62:47] (see v2)
+  int32_t look;
+  uint32_t range, shifts;
+  uint32_t rp, nxt;  // next refill offset, prefetched raw dword
+  const uint8_t *src;
+  uint32_t cap;
+};
+
+template <int I, bool kAlign>
+__device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, bool is_ctx_v, uint32_t r0_v,
+                                              uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
+                                              uint32_t &my_bin, uint32_t j, QuadDec &w) {
+  if (w.look <= 15) {  // refill 32 bits (rare); the dword was loaded at the previous refill
+    const uint64_t add = (uint64_t)__builtin_bswap32(w.nxt) << (15 - w.look);
+    w.hi |= (uint32_t)(add >> 32);
+    w.lo |= (uint32_t)add;
+    w.look += 32;
+    w.rp += 4;
+    w.nxt = lane_load_le32(w.src, w.cap, w.rp);
+  }
+  const uint32_t info = row_bcast<I>(info_v);
+  const uint32_t kq = row_bcast<I>(kq_v);
+  const uint32_t k = kq & 31u, mps = kq >> 5, c2 = info & 15u;
+  const bool cur_ctx = (info & kQDecCtx) != 0;
+  const bool cur_trm = (info & kQDecTrm) != 0;
+  const int ep = (int)((info >> 4) & 1u);
+  {  // decodeBinEP doubles value before comparing (arith_codec.cpp:100-105)
+    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << ep;
+    w.hi = (uint32_t)(v >> 32);
+    w.lo = (uint32_t)v;
+  }
+  const uint32_t t = ((((w.range >> 5) & 15u) * k) + c2) >> 1;
+  const uint32_t rm = w.range - t;
+  const uint32_t sr = rm << 22;
+  const bool nop = (info & kQDecNop) != 0;  // lanes past the end of their substream change nothing
+  const bool ge = w.hi >= sr && !nop;
+  const uint32_t bin = cur_ctx ? (ge ? 1u - mps : mps) : (ge ? 1u : 0u);
+  const int nl = __builtin_clz(t | 1u) - 23;
+  const int nm = (rm < 256u && !nop) ? 1 : 0;  // (after terminate bin 1 range may be < 256, arith_codec.cpp:182-185)
+  const int nsh = ge ? (cur_ctx ? nl : 0) : nm;
+  w.hi -= (ge && !cur_trm) ? sr : 0u;  // terminate bin 1 leaves value untouched (:184-185)
+  w.range = ((ge && cur_ctx) ? t : rm) << nsh;
+  {
+    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << nsh;
+    w.hi = (uint32_t)(v >> 32);
+    w.lo = (uint32_t)v;
+  }
+  w.shifts += (uint32_t)(nsh + ep);
+  w.look -= nsh + ep;
+  if (kAlign && (info & kQDecAlign)) w.range = 256;
+  // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
+  // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
+  const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
+  const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
+  const uint32_t upd = st_v - dlt + (bin ? a_v : 0u);
+  st_v = (key_v == (info >> 16)) ? upd : st_v;
+  const uint32_t q8 = ctx2_q8(st_v);
+  kq_v = is_ctx_v ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+  my_bin = (j == (uint32_t)I) ? bin : my_bin;
+}
+
+template <bool kAlign>
+__device__ __forceinline__ void quad_dec_steps(uint32_t info_v, uint32_t key_v, bool is_ctx_v, uint32_t r0_v,
+                                               uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
+                                               uint32_t &my_bin, uint32_t j, QuadDec &w) {
+#define QSTEP(I) quad_dec_step<I, kAlign>(info_v, key_v, is_ctx_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w)
+  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
+  QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+#undef QSTEP
+}
+
+__global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                       const uint16_t *__restrict__ records,
+                                                       const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
+                                                       cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx[kQuadSubs * kQuadCtxStride];
+  const uint32_t lane = threadIdx.x, row = lane >> 4, j = lane & 15u;
+  const uint32_t sub = blockIdx.x * kQuadSubs + row;
+  const bool live = sub < n_sub;
+  const cabac_substream_desc d = desc[live ? sub : 0];
+  const uint32_t n = live ? d.n_records : 0u;
+  const uint16_t *rec = records + d.rec_offset;
+  uint8_t *out = bins + d.rec_offset;
+  uint32_t *rctx = ctx + row * kQuadCtxStride;
+  {
+    const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
+    const uint32_t iid = d.init_id & 3u;
+    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16)
+      rctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+  }
+  __syncthreads();
+
+  QuadDec w;
+  w.src = bytes + d.byte_offset;
+  w.cap = live ? d.byte_capacity : 0u;
+  {
+    const uint32_t first = __builtin_bswap32(lane_load_le32(w.src, w.cap, 0));  // start(), arith_codec.cpp:60-66
+    w.hi = first >> 1;
+    w.lo = first << 31;
+  }
+  w.look = 16;
+  w.rp = 4;
+  w.nxt = lane_load_le32(w.src, w.cap, 4);
+  w.range = 510;
+  w.shifts = 0;
+  uint32_t bad = 0;
+
+  uint32_t next_rec = j < n ? rec[j] : 0;
+  for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
+    const uint32_t r = next_rec;
+    {
+      const uint32_t nxt = base + 16u + j;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
+    const bool active = base + j < n;
+    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+    const bool is_ctx = id < (uint32_t)kNumCtx;
+    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+    uint32_t st_v = is_ctx ? rctx[id] : 0u;
+    const uint32_t key_v = is_ctx ? id : 0xfffu;
+    const uint32_t r0_v = (st_v & 3u) + 2u, r1_v = ((st_v >> 2) & 7u) + 5u;
+    const uint32_t a_v = ((0x7fffu >> r0_v) & kMask0) | (((0x7fffu >> r1_v) & kMask1) << 16);
+    uint32_t kq_v;
+    {
+      const uint32_t q8 = ctx2_q8(st_v);
+      kq_v = is_ctx ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+    }
+    uint32_t info_v = (0xffeu << 16) | (active ? 0u : kQDecNop);  // key field that matches no lane
+    if (is_ctx) info_v = 8u | kQDecCtx | (id << 16);
+    else if (active && id == CABAC_REC_TRM) info_v |= 4u | kQDecTrm;
+    else if (active && id == CABAC_REC_EP) info_v |= kQDecEp;
+    else if (active && id == CABAC_REC_ALIGN) info_v |= kQDecAlign;
+    const bool any_align = __ballot(active && id == CABAC_REC_ALIGN) != 0;
+    uint32_t my_bin = 0;
+    if (!any_align) quad_dec_steps<false>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
+    else quad_dec_steps<true>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
+    if (is_ctx) rctx[id] = st_v;
+    if (active) out[base + j] = (uint8_t)my_bin;
+  }
+
+  const uint32_t bytes_read = 2u + (w.shifts >> 3);
+  const int32_t bits_needed = (int32_t)(w.shifts & 7u) - 8;
+  uint32_t flags = 0;
+  if (live && (d.init_id & CABAC_SUB_FINISH)) {
+    uint32_t ok = 0;
+    if (bytes_read <= w.cap) {
+      const uint32_t last = w.src[bytes_read - 1];
+      ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
+    }
+    if (!ok) flags |= CABAC_RES_BAD_STOP;
+  }
+  if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;
+  const uint64_t bad_mask = __ballot(bad != 0);
+  if ((bad_mask >> (row * 16u)) & 0xffffull) flags |= CABAC_RES_BAD_RECORD;
+  if (live && j == 0) {
+    cabac_substream_result res;
+    res.n_bits = 8u * bytes_read + (uint32_t)bits_needed;
+    res.flags = flags;
+    results[sub] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint8_t *bytes, cabac_substream_result *results) {
+  hipLaunchKernelGGL(encode_kernel_v4, dim3((n_sub + kQuadSubs - 1) / kQuadSubs), dim3(64), 0, st, n_sub, desc, records,
+                     bytes, results);
+  return hipGetLastError();
+}
+
+hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results) {
+  hipLaunchKernelGGL(decode_kernel_v4, dim3((n_sub + kQuadSubs - 1) / kQuadSubs), dim3(64), 0, st, n_sub, desc, records,
+                     bytes, bins, results);
+  return hipGetLastError();
+}
+
+}  // namespace cabac

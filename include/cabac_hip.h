@@ -97,8 +97,9 @@ typedef struct cabac_substream_desc {
 } cabac_substream_desc;
 
 /* desc.init_id flag bits */
-#define CABAC_SUB_FINISH 0x100u /* encode: run BinEncoderBase::finish() (arith_codec.cpp:339-357) \
-                                   decode: run BinDecoderBase::finish() stop-pattern check (:68-73) */
+#define CABAC_SUB_FINISH 0x100u /* encode: run BinEncoderBase::finish() (arith_codec.cpp:339-357); REQUIRED — a   \
+                                   substream is coded start() .. finish() in one call, output without it is     \
+                                   unspecified.  decode: run BinDecoderBase::finish() stop-pattern check (:68-73) */
 #define CABAC_SUB_ALIGN_RBSP 0x200u /* encode, with FINISH: also OutputBitstream::writeByteAlignment() \
                                        (bit_stream.cpp:152-155): stop bit '1' + zero pad            */
 
