@@ -171,5 +171,9 @@ class CabacHip:
         self._check(self.L.cabac_hip_decode_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_bytes), vp(d_bins),
                                                    vp(d_results)))
 
+    def binarize_device(self, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records):
+        self._check(self.L.cabac_hip_binarize_device(self.h, n_sub, vp(d_se_offset), vp(d_se), vp(d_rec_offset),
+                                                     vp(d_n_records), vp(d_records)))
+
     def ctx_init_device(self, n_sub, d_qp, d_init_id, d_state, d_rate):
         self._check(self.L.cabac_hip_ctx_init_device(self.h, n_sub, vp(d_qp), vp(d_init_id), vp(d_state), vp(d_rate)))

@@ -339,9 +339,17 @@ int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   return CABAC_HIP_OK;
 }
 
-int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t, const uint64_t *, const uint32_t *, const uint64_t *,
-                              uint32_t *, uint16_t *) {
-  return fail(c, CABAC_HIP_ERR_INVALID, "binarize: not built yet");
+int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t n_sub, const uint64_t *d_se_offset, const uint32_t *d_se,
+                              const uint64_t *d_rec_offset, uint32_t *d_n_records, uint16_t *d_records) {
+  if (!c || (n_sub && (!d_se_offset || !d_se || !d_n_records || (d_records && !d_rec_offset))))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 2);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
+  HIP_TRY(c, cabac::launch_binarize(c->stream, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
+  return CABAC_HIP_OK;
 }
 
 }  // extern "C"

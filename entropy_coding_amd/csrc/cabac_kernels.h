@@ -22,5 +22,9 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results);
 
+// device binariser (cabac_binarize.hip)
+hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_offset, const uint32_t *se,
+                           const uint64_t *rec_offset, uint32_t *n_records, uint16_t *records);
+
 }  // namespace cabac
 #endif

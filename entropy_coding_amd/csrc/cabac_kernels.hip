@@ -198,11 +198,7 @@ __global__ __launch_bounds__(64) void encode_kernel_v1(uint32_t n_sub, const cab
   uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
-    const uint32_t r = next_rec;
-    {
-      uint32_t nxt = base + 64u + (uint32_t)lane;
-      next_rec = nxt < n ? rec[nxt] : 0;  // prefetch the next 64 records
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const uint32_t id = r & CABAC_REC_ID_MASK;
     const bool active = (uint32_t)lane < cnt;
     const bool is_ctx = active && id < (uint32_t)kNumCtx;
@@ -213,6 +209,11 @@ __global__ __launch_bounds__(64) void encode_kernel_v1(uint32_t n_sub, const cab
     // per-lane record word for the scalar walk: id | bin << 15 | r0 << 16 | r1 << 24
     const uint32_t info_v = (r & 0xffffu) | (ce.rates << 16);
     const uint32_t key_v = is_ctx ? id : 0xffffu;  // forwarding key
+    {  // prefetch the next 64 records; placed after the uses of `r` so that hipcc's vmcnt(0) wait
+       // in front of them does not also wait for this load
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
 
     for (uint32_t i = 0; i < cnt; i++) {
       const uint32_t info = __builtin_amdgcn_readlane(info_v, i);
@@ -342,11 +343,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v1(uint32_t n_sub, const cab
   uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
-    const uint32_t r = next_rec;
-    {
-      uint32_t nxt = base + 64u + (uint32_t)lane;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const uint32_t id = r & CABAC_REC_ID_MASK;
     const bool active = (uint32_t)lane < cnt;
     const bool is_ctx = active && id < (uint32_t)kNumCtx;
@@ -357,6 +354,11 @@ __global__ __launch_bounds__(64) void decode_kernel_v1(uint32_t n_sub, const cab
     const uint32_t info_v = id | (ce.rates << 16);
     const uint32_t key_v = is_ctx ? id : 0xffffu;
     uint64_t bin_mask = 0;
+    {  // prefetch the next 64 records; placed after the uses of `r` so that hipcc's vmcnt(0) wait
+       // in front of them does not also wait for this load
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
 
     for (uint32_t i = 0; i < cnt; i++) {
       const uint32_t info = __builtin_amdgcn_readlane(info_v, i);
@@ -897,11 +899,7 @@ __global__ __launch_bounds__(64) void encode_kernel_v3(uint32_t n_sub, const cab
   uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
-    const uint32_t r = next_rec;
-    {
-      const uint32_t nxt = base + 64u + (uint32_t)lane;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const bool active = (uint32_t)lane < cnt;
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const uint32_t bin = (r >> 15) & 1u;
@@ -936,6 +934,11 @@ __global__ __launch_bounds__(64) void encode_kernel_v3(uint32_t n_sub, const cab
     if (is_trm) info = (2u << 5) | (bin ? kInfoLps : 0u);
     if (is_ep) info = kInfoEp | (bin ? kInfoEpOne : 0u);
     if (is_align) info = kInfoAlign;
+    {  // prefetch the next 64 records; placed after the uses of `r` so that hipcc's vmcnt(0) wait
+       // in front of them does not also wait for this load
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
     const bool any_align = __ballot(is_align) != 0;
 
     // ---- phase B: the serial low / range chain (wave-uniform) -------------------------------
@@ -1006,11 +1009,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
   uint32_t next_rec = (uint32_t)lane < n ? rec[lane] : 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t cnt = (n - base) < 64u ? (n - base) : 64u;
-    const uint32_t r = next_rec;
-    {
-      const uint32_t nxt = base + 64u + (uint32_t)lane;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const bool active = (uint32_t)lane < cnt;
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const bool is_ctx = id < (uint32_t)kNumCtx;
@@ -1030,6 +1029,11 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
     else if (active && id == CABAC_REC_TRM) info_v = 2u;
     else if (active && id == CABAC_REC_EP) info_v = kDecEp;
     else if (active && id == CABAC_REC_ALIGN) info_v = kDecAlign;
+    {  // prefetch the next 64 records; placed after the uses of `r` so that hipcc's vmcnt(0) wait
+       // in front of them does not also wait for this load
+      const uint32_t nxt = base + 64u + (uint32_t)lane;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
     uint32_t my_bin = 0;
 
     for (uint32_t i = 0; i < cnt; i++) {

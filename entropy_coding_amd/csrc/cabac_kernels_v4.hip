@@ -173,11 +173,7 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
 
   uint32_t next_rec = j < n ? rec[j] : 0;
   for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
-    const uint32_t r = next_rec;
-    {
-      const uint32_t nxt = base + 16u + j;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const bool active = base + j < n;
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const uint32_t bin = (r >> 15) & 1u;
@@ -213,6 +209,12 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
     if (is_ep) info = kQEp | (bin ? kQEpOne : 0u);
     if (is_align) info = kQAlign;
 
+    // prefetch the next 16 records of each row now: the load completes under the serial chain.  (Issued
+    // any earlier, hipcc's s_waitcnt vmcnt(0) in front of the first use of `r` would wait for it too.)
+    {
+      const uint32_t nxt = base + 16u + j;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
     // (b) the serial chain, 4 rows at once
     if (__ballot(is_align) == 0) quad_enc_steps<false>(info, e, writer);
     else quad_enc_steps<true>(info, e, writer);
@@ -371,11 +373,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
 
   uint32_t next_rec = j < n ? rec[j] : 0;
   for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
-    const uint32_t r = next_rec;
-    {
-      const uint32_t nxt = base + 16u + j;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    const uint32_t r = next_rec;  // loaded one step ago
     const bool active = base + j < n;
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const bool is_ctx = id < (uint32_t)kNumCtx;
@@ -395,6 +393,10 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
     else if (active && id == CABAC_REC_EP) info_v |= kQDecEp;
     else if (active && id == CABAC_REC_ALIGN) info_v |= kQDecAlign;
     const bool any_align = __ballot(active && id == CABAC_REC_ALIGN) != 0;
+    {  // prefetch the next step's records (see encode)
+      const uint32_t nxt = base + 16u + j;
+      next_rec = nxt < n ? rec[nxt] : 0;
+    }
     uint32_t my_bin = 0;
     if (!any_align) quad_dec_steps<false>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
     else quad_dec_steps<true>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
