@@ -31,6 +31,25 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DESC_BYTES, RESULT_BYTES = 32, 8
 
 
+def kernel_names(enc_variant, dec_variant, n_sub):
+    """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
+    def pick(v):
+        kind = v & 0xFF
+        if kind == 4 or (kind == 0 and n_sub >= 2048):
+            return "v4"
+        return {1: "v1", 2: "v2"}.get(kind, "v3")
+    return "encode_kernel_" + pick(enc_variant), "decode_kernel_" + pick(dec_variant)
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return t["workloads"][workload][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +123,7 @@ def main():
     n_sub = cfg.n_substreams
     first = rank * n_sub  # weak scaling: rank r codes substreams [r*n_sub, (r+1)*n_sub) of the same generator
     desc, records, bytes_total = build_batch(cfg, first=first, count=n_sub)
+    order = build_batch.last_order  # generator index of each descriptor row (LPT order for mixed lengths)
     n_bins = int(desc["n_records"].astype(np.int64).sum())
     n_slots = int(len(records))  # records/bins buffers include the stagger gaps (never touched)
 
@@ -163,9 +183,10 @@ def main():
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_md5.json")))[cfg.name]
         host_bytes = t_bytes.cpu().numpy()
         hash_match = True
+        row_of = {int(idx): k for k, idx in enumerate(order)}
         for g in gold["substreams"]:
-            s = g["index"] - first
-            if 0 <= s < n_sub:
+            s = row_of.get(g["index"])
+            if s is not None:
                 o, nb = int(desc["byte_offset"][s]), (int(res_e["n_bits"][s]) + 7) // 8
                 hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
         del host_bytes
@@ -194,6 +215,8 @@ def main():
         dec_gbps = bytes_dec / (dec_avg * 1e-3) / 1e9
         dominant = "decode" if dec_avg >= enc_avg else "encode"
         ach = dec_gbps if dominant == "decode" else enc_gbps
+        k_enc, k_dec = kernel_names(args.enc_variant, args.dec_variant, n_sub)
+        k_dom = k_dec if dominant == "decode" else k_enc
         line = {
             "metric": "Mbins/s encode+decode, intra QP%d synthetic bin buffers" % cfg.substream(0)[2],
             "value": round(value, 2),
@@ -224,15 +247,17 @@ def main():
             "hash_match": bool(hash_match and ok),
             "roofline": {
                 "bound": "hbm",
-                "kernel": dominant,
+                "kernel": k_dom,
                 "achieved": round(ach, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 6),
-                "traffic": None,
+                "traffic": measured_traffic(cfg.name, k_dom),  # PMC bytes per launch (profiles/pmc_traffic.json)
                 "algorithmic_bytes_per_launch": bytes_dec if dominant == "decode" else bytes_enc,
-                "other_kernel": {"kernel": "encode" if dominant == "decode" else "decode",
-                                 "achieved": round(enc_gbps if dominant == "decode" else dec_gbps, 3)},
+                "other_kernel": {"kernel": k_enc if dominant == "decode" else k_dec,
+                                 "achieved": round(enc_gbps if dominant == "decode" else dec_gbps, 3),
+                                 "algorithmic_bytes_per_launch": bytes_enc if dominant == "decode" else bytes_dec,
+                                 "traffic": measured_traffic(cfg.name, k_enc if dominant == "decode" else k_dec)},
             },
         }
         if gather_ms is not None:
