@@ -272,8 +272,19 @@ struct QuadDec {   // row-uniform values
   uint32_t cap;
 };
 
+// 0 / ~0 from one bit of x
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask(uint32_t x) {
+  return (uint32_t)((int32_t)(x << (31 - BIT)) >> 31);
+}
+// (a & m) | (b & ~m)  — v_bfi_b32
+__device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
+// One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
+// every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip, and
+// this chain is latency bound.
 template <int I, bool kAlign>
-__device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, bool is_ctx_v, uint32_t r0_v,
+__device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, uint32_t ctxm_v, uint32_t r0_v,
                                               uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
                                               uint32_t &my_bin, uint32_t j, QuadDec &w) {
   if (w.look <= 15) {  // refill 32 bits (rare); the dword was loaded at the previous refill
@@ -282,14 +293,13 @@ __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, b
     w.lo |= (uint32_t)add;
     w.look += 32;
     w.rp += 4;
-    w.nxt = lane_load_le32(w.src, w.cap, w.rp);
+    w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
   }
   const uint32_t info = row_bcast<I>(info_v);
   const uint32_t kq = row_bcast<I>(kq_v);
   const uint32_t k = kq & 31u, mps = kq >> 5, c2 = info & 15u;
-  const bool cur_ctx = (info & kQDecCtx) != 0;
-  const bool cur_trm = (info & kQDecTrm) != 0;
-  const int ep = (int)((info >> 4) & 1u);
+  const uint32_t ctxm = bit_mask<5>(info), trmm = bit_mask<6>(info), nopm = bit_mask<8>(info);
+  const uint32_t ep = (info >> 4) & 1u;
   {  // decodeBinEP doubles value before comparing (arith_codec.cpp:100-105)
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << ep;
     w.hi = (uint32_t)(v >> 32);
@@ -298,35 +308,36 @@ __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, b
   const uint32_t t = ((((w.range >> 5) & 15u) * k) + c2) >> 1;
   const uint32_t rm = w.range - t;
   const uint32_t sr = rm << 22;
-  const bool nop = (info & kQDecNop) != 0;  // lanes past the end of their substream change nothing
-  const bool ge = w.hi >= sr && !nop;
-  const uint32_t bin = cur_ctx ? (ge ? 1u - mps : mps) : (ge ? 1u : 0u);
-  const int nl = __builtin_clz(t | 1u) - 23;
-  const int nm = (rm < 256u && !nop) ? 1 : 0;  // (after terminate bin 1 range may be < 256, arith_codec.cpp:182-185)
-  const int nsh = ge ? (cur_ctx ? nl : 0) : nm;
-  w.hi -= (ge && !cur_trm) ? sr : 0u;  // terminate bin 1 leaves value untouched (:184-185)
-  w.range = ((ge && cur_ctx) ? t : rm) << nsh;
+  const uint32_t gem = (w.hi >= sr ? ~0u : 0u) & ~nopm;      // value >= scaledRange (LPS / bin 1)
+  const uint32_t bin = (gem & 1u) ^ mps;                      // mps == 0 for non-context records
+  const uint32_t nl = (uint32_t)(__builtin_clz(t | 1u) - 23) & ctxm;
+  const uint32_t nm = ((rm >> 8) ^ 1u) & ~nopm;               // rm < 512: 1 iff rm < 256
+  const uint32_t nsh = sel(gem, nl, nm);
+  w.hi -= sr & gem & ~trmm;                                   // terminate bin 1 leaves value untouched (:184-185)
+  w.range = sel(gem & ctxm, t, rm) << nsh;
   {
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << nsh;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
   }
-  w.shifts += (uint32_t)(nsh + ep);
-  w.look -= nsh + ep;
+  w.shifts += nsh + ep;
+  w.look -= (int32_t)(nsh + ep);
   if (kAlign && (info & kQDecAlign)) w.range = 256;
   // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
   // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
   const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
   const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
-  const uint32_t upd = st_v - dlt + (bin ? a_v : 0u);
-  st_v = (key_v == (info >> 16)) ? upd : st_v;
-  const uint32_t q8 = ctx2_q8(st_v);
-  kq_v = is_ctx_v ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+  const uint32_t upd = st_v - dlt + (a_v & (0u - bin));
+  const uint32_t matchm = key_v == (info >> 16) ? ~0u : 0u;
+  st_v = sel(matchm, upd, st_v);
+  const uint32_t sum = (st_v & kMask0) + (st_v >> 16);        // state(), contexts.cpp:939-941
+  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
+  kq_v = ((((sum >> 10) ^ sx) & 31u) | ((sum >> 10) & 32u)) & ctxm_v;
   my_bin = (j == (uint32_t)I) ? bin : my_bin;
 }
 
 template <bool kAlign>
-__device__ __forceinline__ void quad_dec_steps(uint32_t info_v, uint32_t key_v, bool is_ctx_v, uint32_t r0_v,
+__device__ __forceinline__ void quad_dec_steps(uint32_t info_v, uint32_t key_v, uint32_t is_ctx_v, uint32_t r0_v,
                                                uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
                                                uint32_t &my_bin, uint32_t j, QuadDec &w) {
 #define QSTEP(I) quad_dec_step<I, kAlign>(info_v, key_v, is_ctx_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w)
@@ -360,13 +371,15 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
   w.src = bytes + d.byte_offset;
   w.cap = live ? d.byte_capacity : 0u;
   {
-    const uint32_t first = __builtin_bswap32(lane_load_le32(w.src, w.cap, 0));  // start(), arith_codec.cpp:60-66
+    // start(), arith_codec.cpp:60-66.  Input is read as aligned dwords that contain at least one valid byte
+    // (cabac_hip.h: the bytes buffer is readable up to the next multiple of 4 past every substream).
+    const uint32_t first = __builtin_bswap32(w.cap ? *reinterpret_cast<const uint32_t *>(w.src) : 0u);
     w.hi = first >> 1;
     w.lo = first << 31;
   }
   w.look = 16;
   w.rp = 4;
-  w.nxt = lane_load_le32(w.src, w.cap, 4);
+  w.nxt = 4u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 4) : 0u;
   w.range = 510;
   w.shifts = 0;
   uint32_t bad = 0;
@@ -398,8 +411,9 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
       next_rec = nxt < n ? rec[nxt] : 0;
     }
     uint32_t my_bin = 0;
-    if (!any_align) quad_dec_steps<false>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
-    else quad_dec_steps<true>(info_v, key_v, is_ctx, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
+    const uint32_t ctxm_v = is_ctx ? ~0u : 0u;
+    if (!any_align) quad_dec_steps<false>(info_v, key_v, ctxm_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
+    else quad_dec_steps<true>(info_v, key_v, ctxm_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
     if (is_ctx) rctx[id] = st_v;
     if (active) out[base + j] = (uint8_t)my_bin;
   }

@@ -92,6 +92,9 @@ typedef struct cabac_substream_desc {
   uint64_t byte_offset;   /* first byte of this substream in bytes[]                 */
   uint32_t n_records;     /* number of bin records                                    */
   uint32_t byte_capacity; /* encode: room at byte_offset; decode: valid input bytes   */
+                          /* byte_offset must be a multiple of 16; decode reads whole  */
+                          /* aligned dwords, so bytes[] must be readable up to the next */
+                          /* multiple of 4 past byte_offset + byte_capacity             */
   int32_t qp;             /* slice QP for Ctx::init (clipped to 0..63, contexts.cpp:1010) */
   uint32_t init_id;       /* bits 1..0: CABAC_INIT_B/P/I;  bits 31..8: CABAC_SUB_* flags */
 } cabac_substream_desc;
