@@ -116,7 +116,7 @@ __device__ __forceinline__ void quad_enc_step(uint32_t info_v, QuadEnc &e, bool 
   e.low = (e.low << ep) + ((info & kQEpOne) ? e.range : 0u);  // encodeBinEP (arith_codec.cpp:389-399)
   if (kAlign && (info & kQAlign)) e.range = 256;
   e.pend += nb + (int)ep;
-  if (e.pend >= 16) quad_flush16(e, writer);
+  if (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);  // cold: laid out of line so the hot path falls through
 }
 
 template <bool kAlign>
@@ -287,7 +287,7 @@ template <int I, bool kAlign>
 __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, uint32_t ctxm_v, uint32_t r0_v,
                                               uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
                                               uint32_t &my_bin, uint32_t j, QuadDec &w) {
-  if (w.look <= 15) {  // refill 32 bits (rare); the dword was loaded at the previous refill
+  if (__builtin_expect(w.look <= 15, 0)) {  // refill 32 bits (rare, cold); the dword was loaded at the previous refill
     const uint64_t add = (uint64_t)__builtin_bswap32(w.nxt) << (15 - w.look);
     w.hi |= (uint32_t)(add >> 32);
     w.lo |= (uint32_t)add;
