@@ -54,7 +54,7 @@ __device__ __forceinline__ uint64_t match_any_bits(uint32_t key) {
 enum : uint32_t { kQLps = 0x200u, kQEp = 0x400u, kQEpOne = 0x800u, kQAlign = 0x1000u };  // bits 4..0 k, 8..5 2c
 
 struct QuadEnc {       // row-uniform values
-  uint32_t low;        // exact code value: 9 + pend (+1 carry) bits
+  uint64_t low;        // exact code value: 9 + pend (+1 carry) bits; pend <= 15 + 4*7 between flush checks
   uint32_t range;
   int32_t pend;        // bits shifted since the last 16-bit unit was peeled off (< 16 between steps)
   uint32_t buf;        // buffered unit
@@ -84,8 +84,8 @@ __device__ __forceinline__ void quad_put16(QuadEnc &e, uint32_t unit, bool write
 // peel 16 bits off the top of low; delayed carry as writeOut (arith_codec.cpp:524-546) in base 2^16
 __device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
   const uint32_t sh = (uint32_t)(9 + e.pend - 16);
-  const uint32_t lead = e.low >> sh;  // carry + 16 bits
-  e.low &= (1u << sh) - 1u;
+  const uint32_t lead = (uint32_t)(e.low >> sh);  // carry + 16 bits
+  e.low &= (1ull << sh) - 1ull;
   e.pend -= 16;
   const bool is_ff = lead == 0xffffu;
   const bool emit = !is_ff && e.nbuf > 0;
@@ -116,7 +116,11 @@ __device__ __forceinline__ void quad_enc_step(uint32_t info_v, QuadEnc &e, bool 
   e.low = (e.low << ep) + ((info & kQEpOne) ? e.range : 0u);  // encodeBinEP (arith_codec.cpp:389-399)
   if (kAlign && (info & kQAlign)) e.range = 256;
   e.pend += nb + (int)ep;
-  if (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);  // cold: laid out of line so the hot path falls through
+  // output check only every 4th bin: 4 bins shift at most 28 bits, which the 64-bit low absorbs, and the
+  // three steps in between stay in one basic block, so hipcc can overlap their independent parts
+  if ((I & 3) == 3) {
+    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
+  }
 }
 
 template <bool kAlign>
@@ -224,16 +228,16 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   uint32_t n_bits = 0;
   if (live) {
     const uint32_t total = (uint32_t)(9 + e.pend);
-    if ((e.low >> total) & 1u) {
+    if ((e.low >> total) & 1ull) {
       quad_put16(e, e.buf + 1u, writer);
       for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0x0000u, writer);
-      e.low -= 1u << total;
+      e.low -= 1ull << total;
     } else {
       if (e.nbuf > 0) quad_put16(e, e.buf, writer);
       for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0xffffu, writer);
     }
     uint32_t nb = (uint32_t)(e.pend + 1);  // write(low >> 8, 24 - bitsLeft)
-    const uint32_t v = e.low >> 8;
+    const uint32_t v = (uint32_t)(e.low >> 8);
     while (nb >= 8) {
       quad_put_byte(e, (v >> (nb - 8)) & 0xffu, writer);
       nb -= 8;
