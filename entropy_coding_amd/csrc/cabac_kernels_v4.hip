@@ -34,7 +34,7 @@ constexpr uint32_t kQuadCtxStride = 380; // LDS words per row context store (379
 template <int I>
 __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
   // lane I of every 16-lane row -> all lanes of that row (DPP_ROW_NEWBCAST0 = 0x150, gfx90a+)
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, true);  // bound_ctrl: no old-value init
 }
 
 template <int BITS>
@@ -49,9 +49,16 @@ __device__ __forceinline__ uint64_t match_any_bits(uint32_t key) {
   return m;
 }
 
+// 0 / ~0 from one bit of x
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask(uint32_t x) {
+  return (uint32_t)((int32_t)(x << (31 - BIT)) >> 31);
+}
+// (a & m) | (b & ~m)  — v_bfi_b32
+__device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
 // ---------------------------------------------------------------------------------------------
 // encode
-enum : uint32_t { kQLps = 0x200u, kQEp = 0x400u, kQEpOne = 0x800u, kQAlign = 0x1000u };  // bits 4..0 k, 8..5 2c
 
 struct QuadEnc {       // row-uniform values
   uint64_t low;        // exact code value: 9 + pend (+1 carry) bits; pend <= 15 + 4*7 between flush checks
@@ -100,22 +107,32 @@ __device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
   }
 }
 
+// Per-lane fields of one bin for the chain (phase A fills them; all zero = no-op step)
+struct QuadEncInfo {
+  uint32_t k;     // LPS factor (state folded to 0..127) >> 2; 0 for bypass / terminate
+  uint32_t c2;    // 2 * constant term of the LPS width: 8 context bin, 4 terminate bin, 0 bypass
+  uint32_t lpsm;  // ~0 if this bin takes the LPS path (context: bin != mps; terminate: bin == 1)
+  uint32_t ep;    // 1 for a bypass bin
+  uint32_t pem;   // ~0 for a bypass bin with value 1
+  uint32_t alm;   // ~0 for an align() record
+};
+
+// One chain step for the four rows.  The fields reach the row by DPP row broadcasts; masks are used
+// with and/bfi (no compares, no exec regions): the wave is alone on its SIMD and every VALU->SALU->EXEC
+// round trip would sit on the critical path.
 template <int I, bool kAlign>
-__device__ __forceinline__ void quad_enc_step(uint32_t info_v, QuadEnc &e, bool writer) {
-  const uint32_t info = row_bcast<I>(info_v);
-  const uint32_t k = info & 31u, c2 = (info >> 5) & 15u;
-  const uint32_t t = ((((e.range >> 5) & 15u) * k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+__device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, bool writer) {
+  const uint32_t k = row_bcast<I>(f.k), c2 = row_bcast<I>(f.c2), lpsm = row_bcast<I>(f.lpsm), ep = row_bcast<I>(f.ep);
+  const uint32_t t = (__umul24((e.range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
   const uint32_t rm = e.range - t;
-  const bool lps = (info & kQLps) != 0;
-  const int nl = __builtin_clz(t | 1u) - 23;  // getRenormBitsLPS (contexts.cpp:952-954); unused when t == 0
-  const int nm = rm < 256u ? 1 : 0;
-  const int nb = lps ? nl : nm;
-  e.low = (e.low + (lps ? rm : 0u)) << nb;
-  e.range = (lps ? t : rm) << nb;
-  const uint32_t ep = (info >> 10) & 1u;
-  e.low = (e.low << ep) + ((info & kQEpOne) ? e.range : 0u);  // encodeBinEP (arith_codec.cpp:389-399)
-  if (kAlign && (info & kQAlign)) e.range = 256;
-  e.pend += nb + (int)ep;
+  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23);  // getRenormBitsLPS (contexts.cpp:952-954); masked out when t == 0
+  const uint32_t nm = (rm >> 8) ^ 1u;                     // rm < 512: 1 iff rm < 256
+  const uint32_t nb = sel(lpsm, nl, nm);
+  e.low = (e.low + (rm & lpsm)) << nb;
+  e.range = sel(lpsm, t, rm) << nb;
+  e.low = (e.low << ep) + (e.range & row_bcast<I>(f.pem));  // encodeBinEP (arith_codec.cpp:389-399)
+  if (kAlign) e.range = sel(row_bcast<I>(f.alm), 256u, e.range);
+  e.pend += (int32_t)(nb + ep);
   // output check only every 4th bin: 4 bins shift at most 28 bits, which the 64-bit low absorbs, and the
   // three steps in between stay in one basic block, so hipcc can overlap their independent parts
   if ((I & 3) == 3) {
@@ -124,23 +141,23 @@ __device__ __forceinline__ void quad_enc_step(uint32_t info_v, QuadEnc &e, bool 
 }
 
 template <bool kAlign>
-__device__ __forceinline__ void quad_enc_steps(uint32_t info_v, QuadEnc &e, bool writer) {
-  quad_enc_step<0, kAlign>(info_v, e, writer);
-  quad_enc_step<1, kAlign>(info_v, e, writer);
-  quad_enc_step<2, kAlign>(info_v, e, writer);
-  quad_enc_step<3, kAlign>(info_v, e, writer);
-  quad_enc_step<4, kAlign>(info_v, e, writer);
-  quad_enc_step<5, kAlign>(info_v, e, writer);
-  quad_enc_step<6, kAlign>(info_v, e, writer);
-  quad_enc_step<7, kAlign>(info_v, e, writer);
-  quad_enc_step<8, kAlign>(info_v, e, writer);
-  quad_enc_step<9, kAlign>(info_v, e, writer);
-  quad_enc_step<10, kAlign>(info_v, e, writer);
-  quad_enc_step<11, kAlign>(info_v, e, writer);
-  quad_enc_step<12, kAlign>(info_v, e, writer);
-  quad_enc_step<13, kAlign>(info_v, e, writer);
-  quad_enc_step<14, kAlign>(info_v, e, writer);
-  quad_enc_step<15, kAlign>(info_v, e, writer);
+__device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e, bool writer) {
+  quad_enc_step<0, kAlign>(f, e, writer);
+  quad_enc_step<1, kAlign>(f, e, writer);
+  quad_enc_step<2, kAlign>(f, e, writer);
+  quad_enc_step<3, kAlign>(f, e, writer);
+  quad_enc_step<4, kAlign>(f, e, writer);
+  quad_enc_step<5, kAlign>(f, e, writer);
+  quad_enc_step<6, kAlign>(f, e, writer);
+  quad_enc_step<7, kAlign>(f, e, writer);
+  quad_enc_step<8, kAlign>(f, e, writer);
+  quad_enc_step<9, kAlign>(f, e, writer);
+  quad_enc_step<10, kAlign>(f, e, writer);
+  quad_enc_step<11, kAlign>(f, e, writer);
+  quad_enc_step<12, kAlign>(f, e, writer);
+  quad_enc_step<13, kAlign>(f, e, writer);
+  quad_enc_step<14, kAlign>(f, e, writer);
+  quad_enc_step<15, kAlign>(f, e, writer);
 }
 
 __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
@@ -207,12 +224,13 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
     if (is_ctx && is_last) rctx[id] = ctx2_update(st, bin);
     const uint32_t q8 = ctx2_q8(st);
     const uint32_t mps = q8 >> 7;
-    uint32_t info = 0;  // inactive lanes: t = 0, no shift — a no-op step
-    if (is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) ? kQLps : 0u);
-    if (is_trm) info = (4u << 5) | (bin ? kQLps : 0u);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
-    if (is_ep) info = kQEp | (bin ? kQEpOne : 0u);
-    if (is_align) info = kQAlign;
-
+    QuadEncInfo f;  // inactive lanes: all zero — a no-op step (t = 0, no shift)
+    f.k = is_ctx ? ctx2_k(q8) : 0u;
+    f.c2 = is_ctx ? 8u : (is_trm ? 4u : 0u);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
+    f.lpsm = ((is_ctx && (bin ^ mps)) || (is_trm && bin)) ? ~0u : 0u;
+    f.ep = is_ep ? 1u : 0u;
+    f.pem = (is_ep && bin) ? ~0u : 0u;
+    f.alm = is_align ? ~0u : 0u;
     // prefetch the next 16 records of each row now: the load completes under the serial chain.  (Issued
     // any earlier, hipcc's s_waitcnt vmcnt(0) in front of the first use of `r` would wait for it too.)
     {
@@ -220,8 +238,8 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
       next_rec = nxt < n ? rec[nxt] : 0;
     }
     // (b) the serial chain, 4 rows at once
-    if (__ballot(is_align) == 0) quad_enc_steps<false>(info, e, writer);
-    else quad_enc_steps<true>(info, e, writer);
+    if (__ballot(is_align) == 0) quad_enc_steps<false>(f, e, writer);
+    else quad_enc_steps<true>(f, e, writer);
   }
 
   // finish(), arith_codec.cpp:339-357, on the exact code value
@@ -271,18 +289,10 @@ struct QuadDec {   // row-uniform values
   uint32_t hi, lo;   // 64-bit window: value in [62:47] (see v2)
   int32_t look;
   uint32_t range, shifts;
-  uint32_t rp, nxt;  // next refill offset, prefetched raw dword
+  uint32_t rp, nxt;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds it
   const uint8_t *src;
   uint32_t cap;
 };
-
-// 0 / ~0 from one bit of x
-template <int BIT>
-__device__ __forceinline__ uint32_t bit_mask(uint32_t x) {
-  return (uint32_t)((int32_t)(x << (31 - BIT)) >> 31);
-}
-// (a & m) | (b & ~m)  — v_bfi_b32
-__device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
 // every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip, and
@@ -291,13 +301,18 @@ template <int I, bool kAlign>
 __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, uint32_t ctxm_v, uint32_t r0_v,
                                               uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
                                               uint32_t &my_bin, uint32_t j, QuadDec &w) {
-  if (__builtin_expect(w.look <= 15, 0)) {  // refill 32 bits (rare, cold); the dword was loaded at the previous refill
-    const uint64_t add = (uint64_t)__builtin_bswap32(w.nxt) << (15 - w.look);
-    w.hi |= (uint32_t)(add >> 32);
-    w.lo |= (uint32_t)add;
-    w.look += 32;
-    w.rp += 4;
-    w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
+  // input check only every 4th bin (4 bins consume at most 28 bits): 16-bit units are appended while fewer
+  // than 32 look-ahead bits are valid, so that the three steps in between stay in one basic block
+  if ((I & 3) == 0) {
+    while (__builtin_expect(w.look <= 31, 0)) {
+      const uint32_t half = (w.rp & 2u) ? (w.nxt >> 16) : (w.nxt & 0xffffu);
+      const uint64_t add = (uint64_t)(((half & 0xffu) << 8) | (half >> 8)) << (31 - w.look);  // big-endian unit
+      w.hi |= (uint32_t)(add >> 32);
+      w.lo |= (uint32_t)add;
+      w.look += 16;
+      w.rp += 2;
+      if ((w.rp & 2u) == 0u) w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
+    }
   }
   const uint32_t info = row_bcast<I>(info_v);
   const uint32_t kq = row_bcast<I>(kq_v);
@@ -309,7 +324,7 @@ __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, u
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
   }
-  const uint32_t t = ((((w.range >> 5) & 15u) * k) + c2) >> 1;
+  const uint32_t t = (__umul24((w.range >> 5) & 15u, k) + c2) >> 1;
   const uint32_t rm = w.range - t;
   const uint32_t sr = rm << 22;
   const uint32_t gem = (w.hi >= sr ? ~0u : 0u) & ~nopm;      // value >= scaledRange (LPS / bin 1)
