@@ -283,24 +283,35 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
 
 // ---------------------------------------------------------------------------------------------
 // decode
-enum : uint32_t { kQDecEp = 0x10u, kQDecCtx = 0x20u, kQDecTrm = 0x40u, kQDecAlign = 0x80u, kQDecNop = 0x100u };  // bits 3..0 = 2c, 27..16 = key
 
 struct QuadDec {   // row-uniform values
   uint32_t hi, lo;   // 64-bit window: value in [62:47] (see v2)
   int32_t look;
-  uint32_t range, shifts;
+  uint32_t range;
   uint32_t rp, nxt;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds it
   const uint8_t *src;
   uint32_t cap;
 };
 
+// Per-lane fields of one record for the decode chain
+struct QuadDecInfo {
+  uint32_t c2;    // 2 * constant term of the LPS width: 8 context bin, 4 terminate bin, 0 bypass / none
+  uint32_t ep;    // 1 for a bypass bin
+  uint32_t ctxm;  // ~0 for a context-coded bin
+  uint32_t ntrm;  // 0 for a terminate bin, ~0 otherwise
+  uint32_t actm;  // ~0 for a real record, 0 past the end of the substream (the step changes nothing)
+  uint32_t alm;   // ~0 for an align() record
+  uint32_t key;   // ctxId of a context bin; 0xfff otherwise
+};
+
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
 // every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip, and
-// this chain is latency bound.
+// this chain is latency bound.  Per-lane state: st_v (packed context word of the lane's own record),
+// k_v / mps_v derived from it.
 template <int I, bool kAlign>
-__device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, uint32_t ctxm_v, uint32_t r0_v,
-                                              uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
-                                              uint32_t &my_bin, uint32_t j, QuadDec &w) {
+__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_v, uint32_t r1_v, uint32_t a_v,
+                                              uint32_t &st_v, uint32_t &k_v, uint32_t &mps_v, uint32_t &my_bin,
+                                              uint32_t j, QuadDec &w) {
   // input check only every 4th bin (4 bins consume at most 28 bits): 16-bit units are appended while fewer
   // than 32 look-ahead bits are valid, so that the three steps in between stay in one basic block
   if ((I & 3) == 0) {
@@ -314,11 +325,7 @@ __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, u
       if ((w.rp & 2u) == 0u) w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
     }
   }
-  const uint32_t info = row_bcast<I>(info_v);
-  const uint32_t kq = row_bcast<I>(kq_v);
-  const uint32_t k = kq & 31u, mps = kq >> 5, c2 = info & 15u;
-  const uint32_t ctxm = bit_mask<5>(info), trmm = bit_mask<6>(info), nopm = bit_mask<8>(info);
-  const uint32_t ep = (info >> 4) & 1u;
+  const uint32_t k = row_bcast<I>(k_v), c2 = row_bcast<I>(f.c2), ep = row_bcast<I>(f.ep);
   {  // decodeBinEP doubles value before comparing (arith_codec.cpp:100-105)
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << ep;
     w.hi = (uint32_t)(v >> 32);
@@ -327,39 +334,38 @@ __device__ __forceinline__ void quad_dec_step(uint32_t info_v, uint32_t key_v, u
   const uint32_t t = (__umul24((w.range >> 5) & 15u, k) + c2) >> 1;
   const uint32_t rm = w.range - t;
   const uint32_t sr = rm << 22;
-  const uint32_t gem = (w.hi >= sr ? ~0u : 0u) & ~nopm;      // value >= scaledRange (LPS / bin 1)
-  const uint32_t bin = (gem & 1u) ^ mps;                      // mps == 0 for non-context records
-  const uint32_t nl = (uint32_t)(__builtin_clz(t | 1u) - 23) & ctxm;
-  const uint32_t nm = ((rm >> 8) ^ 1u) & ~nopm;               // rm < 512: 1 iff rm < 256
+  const uint32_t gem = (w.hi >= sr ? ~0u : 0u) & row_bcast<I>(f.actm);  // value >= scaledRange (LPS / bin 1)
+  const uint32_t bin = (gem & 1u) ^ row_bcast<I>(mps_v);                 // mps == 0 for non-context records
+  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23) & row_bcast<I>(f.ctxm);
+  const uint32_t nm = ((rm >> 8) ^ 1u) & row_bcast<I>(f.actm);            // rm < 512: 1 iff rm < 256
   const uint32_t nsh = sel(gem, nl, nm);
-  w.hi -= sr & gem & ~trmm;                                   // terminate bin 1 leaves value untouched (:184-185)
-  w.range = sel(gem & ctxm, t, rm) << nsh;
+  w.hi -= (sr & gem) & row_bcast<I>(f.ntrm);                              // terminate bin 1 leaves value untouched (:184-185)
+  w.range = sel(gem & row_bcast<I>(f.ctxm), t, rm) << nsh;
   {
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << nsh;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
   }
-  w.shifts += nsh + ep;
   w.look -= (int32_t)(nsh + ep);
-  if (kAlign && (info & kQDecAlign)) w.range = 256;
+  if (kAlign) w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
   // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
   // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
   const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
   const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
   const uint32_t upd = st_v - dlt + (a_v & (0u - bin));
-  const uint32_t matchm = key_v == (info >> 16) ? ~0u : 0u;
-  st_v = sel(matchm, upd, st_v);
-  const uint32_t sum = (st_v & kMask0) + (st_v >> 16);        // state(), contexts.cpp:939-941
-  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
-  kq_v = ((((sum >> 10) ^ sx) & 31u) | ((sum >> 10) & 32u)) & ctxm_v;
+  st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
+  const uint32_t sum = (st_v & kMask0) + (st_v >> 16);           // state(), contexts.cpp:939-941
+  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);     // 0 / ~0 from the MPS bit (bit 15)
+  k_v = (((sum >> 10) ^ sx) & 31u) & f.ctxm;
+  mps_v = (sum >> 15) & f.ctxm & 1u;
   my_bin = (j == (uint32_t)I) ? bin : my_bin;
 }
 
 template <bool kAlign>
-__device__ __forceinline__ void quad_dec_steps(uint32_t info_v, uint32_t key_v, uint32_t is_ctx_v, uint32_t r0_v,
-                                               uint32_t r1_v, uint32_t a_v, uint32_t &st_v, uint32_t &kq_v,
-                                               uint32_t &my_bin, uint32_t j, QuadDec &w) {
-#define QSTEP(I) quad_dec_step<I, kAlign>(info_v, key_v, is_ctx_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w)
+__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0_v, uint32_t r1_v, uint32_t a_v,
+                                               uint32_t &st_v, uint32_t &k_v, uint32_t &mps_v, uint32_t &my_bin,
+                                               uint32_t j, QuadDec &w) {
+#define QSTEP(I) quad_dec_step<I, kAlign>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w)
   QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
   QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
 #undef QSTEP
@@ -400,7 +406,6 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
   w.rp = 4;
   w.nxt = 4u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 4) : 0u;
   w.range = 510;
-  w.shifts = 0;
   uint32_t bad = 0;
 
   uint32_t next_rec = j < n ? rec[j] : 0;
@@ -411,34 +416,40 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
     const bool is_ctx = id < (uint32_t)kNumCtx;
     if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
     uint32_t st_v = is_ctx ? rctx[id] : 0u;
-    const uint32_t key_v = is_ctx ? id : 0xfffu;
     const uint32_t r0_v = (st_v & 3u) + 2u, r1_v = ((st_v >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0_v) & kMask0) | (((0x7fffu >> r1_v) & kMask1) << 16);
-    uint32_t kq_v;
+    const bool is_trm = active && id == CABAC_REC_TRM;
+    const bool is_align = active && id == CABAC_REC_ALIGN;
+    QuadDecInfo f;
+    f.c2 = is_ctx ? 8u : (is_trm ? 4u : 0u);
+    f.ep = (active && id == CABAC_REC_EP) ? 1u : 0u;
+    f.ctxm = is_ctx ? ~0u : 0u;
+    f.ntrm = is_trm ? 0u : ~0u;
+    f.actm = active ? ~0u : 0u;
+    f.alm = is_align ? ~0u : 0u;
+    f.key = is_ctx ? id : 0xfffu;
+    uint32_t k_v, mps_v;
     {
       const uint32_t q8 = ctx2_q8(st_v);
-      kq_v = is_ctx ? (ctx2_k(q8) | ((q8 >> 7) << 5)) : 0u;
+      k_v = is_ctx ? ctx2_k(q8) : 0u;
+      mps_v = is_ctx ? (q8 >> 7) : 0u;
     }
-    uint32_t info_v = (0xffeu << 16) | (active ? 0u : kQDecNop);  // key field that matches no lane
-    if (is_ctx) info_v = 8u | kQDecCtx | (id << 16);
-    else if (active && id == CABAC_REC_TRM) info_v |= 4u | kQDecTrm;
-    else if (active && id == CABAC_REC_EP) info_v |= kQDecEp;
-    else if (active && id == CABAC_REC_ALIGN) info_v |= kQDecAlign;
-    const bool any_align = __ballot(active && id == CABAC_REC_ALIGN) != 0;
+    const bool any_align = __ballot(is_align) != 0;
     {  // prefetch the next step's records (see encode)
       const uint32_t nxt = base + 16u + j;
       next_rec = nxt < n ? rec[nxt] : 0;
     }
     uint32_t my_bin = 0;
-    const uint32_t ctxm_v = is_ctx ? ~0u : 0u;
-    if (!any_align) quad_dec_steps<false>(info_v, key_v, ctxm_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
-    else quad_dec_steps<true>(info_v, key_v, ctxm_v, r0_v, r1_v, a_v, st_v, kq_v, my_bin, j, w);
+    if (!any_align) quad_dec_steps<false>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w);
+    else quad_dec_steps<true>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w);
     if (is_ctx) rctx[id] = st_v;
     if (active) out[base + j] = (uint8_t)my_bin;
   }
 
-  const uint32_t bytes_read = 2u + (w.shifts >> 3);
-  const int32_t bits_needed = (int32_t)(w.shifts & 7u) - 8;
+  // bits shifted so far: everything moved into the window (8 * rp) minus value (16) minus look-ahead
+  const uint32_t shifts = 8u * w.rp - 16u - (uint32_t)w.look;
+  const uint32_t bytes_read = 2u + (shifts >> 3);  // the reference's counters (arith_codec.cpp:257-260)
+  const int32_t bits_needed = (int32_t)(shifts & 7u) - 8;
   uint32_t flags = 0;
   if (live && (d.init_id & CABAC_SUB_FINISH)) {
     uint32_t ok = 0;
