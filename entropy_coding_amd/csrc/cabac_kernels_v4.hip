@@ -352,8 +352,10 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
   const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
   const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
-  const uint32_t upd = st_v - dlt + (a_v & (0u - bin));
+  uint32_t upd = st_v - dlt + (a_v & (0u - bin));
+  asm volatile("" : "+v"(upd));   // keep the update and the re-derivation below unconditional: hipcc would
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
+  asm volatile("" : "+v"(st_v));  // otherwise wrap them in an exec region (SALU round trip + branch per bin)
   const uint32_t sum = (st_v & kMask0) + (st_v >> 16);           // state(), contexts.cpp:939-941
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);     // 0 / ~0 from the MPS bit (bit 15)
   k_v = (((sum >> 10) ^ sx) & 31u) & f.ctxm;
