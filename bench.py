@@ -33,12 +33,12 @@ DESC_BYTES, RESULT_BYTES = 32, 8
 
 def kernel_names(enc_variant, dec_variant, n_sub):
     """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
-    def pick(v):
+    def pick(v, auto_v4):
         kind = v & 0xFF
-        if kind == 4 or (kind == 0 and n_sub >= 2048):
+        if kind == 4 or (kind == 0 and auto_v4):
             return "v4"
         return {1: "v1", 2: "v2"}.get(kind, "v3")
-    return "encode_kernel_" + pick(enc_variant), "decode_kernel_" + pick(dec_variant)
+    return "encode_kernel_" + pick(enc_variant, n_sub > 2048), "decode_kernel_" + pick(dec_variant, True)
 
 
 def measured_traffic(workload, kernel):
