@@ -114,10 +114,19 @@ def main():
     from entropy_coding_amd import capi
     from entropy_coding_amd.workload import CONFIGS, build_batch
 
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): CABAC_BENCH_BACKEND=gloo runs the
+    # collectives on CPU tensors, CABAC_BENCH_SAME_DEVICE=1 puts every rank on cuda:0.
+    backend = os.environ.get("CABAC_BENCH_BACKEND", "nccl")
+    if os.environ.get("CABAC_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.workload]
     n_sub = cfg.n_substreams
@@ -161,7 +170,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -194,14 +203,14 @@ def main():
     # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
     gather_ms = None
     if world > 1:
-        sizes = t_res_e.view(-1, 2)[:, 0].contiguous()
+        sizes = t_res_e.view(-1, 2)[:, 0].contiguous().to(coll_dev)
         allsz = [torch.empty_like(sizes) for _ in range(world)]
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         dist.all_gather(allsz, sizes)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        flag = torch.tensor([1 if ok else 0], device="cuda")
+        flag = torch.tensor([1 if ok else 0], device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
