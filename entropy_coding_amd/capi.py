@@ -24,6 +24,7 @@ EXPORTS = [
     "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
     "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
+    "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
 ]
 
 _lib = None
@@ -64,6 +65,9 @@ def load_library():
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
     L.cabac_hip_last_kernel_ms.argtypes = [vp]
+    L.cabac_hip_assemble_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint64, vp]
+    L.cabac_hip_split_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
+    L.cabac_hip_count_emulations_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.cabac_synth_records.restype = None
@@ -174,6 +178,17 @@ class CabacHip:
     def binarize_device(self, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records):
         self._check(self.L.cabac_hip_binarize_device(self.h, n_sub, vp(d_se_offset), vp(d_se), vp(d_rec_offset),
                                                      vp(d_n_records), vp(d_records)))
+
+    def assemble_device(self, n_sub, d_desc, d_results, d_bytes, d_payload, payload_capacity, d_offsets):
+        self._check(self.L.cabac_hip_assemble_device(self.h, n_sub, vp(d_desc), vp(d_results), vp(d_bytes), vp(d_payload),
+                                                     payload_capacity, vp(d_offsets)))
+
+    def split_device(self, n_sub, d_desc, d_offsets, d_payload, d_bytes):
+        self._check(self.L.cabac_hip_split_device(self.h, n_sub, vp(d_desc), vp(d_offsets), vp(d_payload), vp(d_bytes)))
+
+    def count_emulations_device(self, n_sub, d_desc, d_results, d_bytes, d_counts):
+        self._check(self.L.cabac_hip_count_emulations_device(self.h, n_sub, vp(d_desc), vp(d_results), vp(d_bytes),
+                                                             vp(d_counts)))
 
     def ctx_init_device(self, n_sub, d_qp, d_init_id, d_state, d_rate):
         self._check(self.L.cabac_hip_ctx_init_device(self.h, n_sub, vp(d_qp), vp(d_init_id), vp(d_state), vp(d_rate)))

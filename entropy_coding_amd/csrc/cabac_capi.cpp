@@ -260,6 +260,33 @@ int cabac_hip_profile_read(cabac_hip_ctx *c, int32_t *kind, float *ms, uint32_t 
   return (int)n;
 }
 
+int cabac_hip_assemble_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                              const cabac_substream_result *d_results, const uint8_t *d_bytes, uint8_t *d_payload,
+                              uint64_t payload_capacity, uint64_t *d_offsets) {
+  if (!c || !d_offsets || (n_sub && (!d_desc || !d_results || !d_bytes || !d_payload)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, cabac::launch_assemble(c->stream, n_sub, d_desc, d_results, d_bytes, d_payload, payload_capacity, d_offsets));
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_split_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint64_t *d_offsets,
+                           const uint8_t *d_payload, uint8_t *d_bytes) {
+  if (!c || (n_sub && (!d_desc || !d_offsets || !d_payload || !d_bytes))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, cabac::launch_split(c->stream, n_sub, d_desc, d_offsets, d_payload, d_bytes));
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_count_emulations_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                      const cabac_substream_result *d_results, const uint8_t *d_bytes,
+                                      uint32_t *d_counts) {
+  if (!c || (n_sub && (!d_desc || !d_results || !d_bytes || !d_counts))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, cabac::launch_count_emulations(c->stream, n_sub, d_desc, d_results, d_bytes, d_counts));
+  return CABAC_HIP_OK;
+}
+
 float cabac_hip_last_kernel_ms(cabac_hip_ctx *c) {
   if (!c || !c->timed) return -1.0f;
   DeviceGuard g(c->device);

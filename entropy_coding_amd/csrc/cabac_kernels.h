@@ -26,5 +26,14 @@ hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_offset, const uint32_t *se,
                            const uint64_t *rec_offset, uint32_t *n_records, uint16_t *records);
 
+// substream assembly (cabac_assemble.hip)
+hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
+                           const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,
+                           uint64_t payload_capacity, uint64_t *offsets);
+hipError_t launch_split(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint64_t *offsets,
+                        const uint8_t *payload, uint8_t *bytes);
+hipError_t launch_count_emulations(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
+                                   const cabac_substream_result *results, const uint8_t *bytes, uint32_t *counts);
+
 }  // namespace cabac
 #endif

@@ -181,6 +181,23 @@ int cabac_hip_binarize_device(cabac_hip_ctx *ctx, uint32_t n_sub, const uint64_t
                               const uint32_t *d_se, const uint64_t *d_rec_offset,
                               uint32_t *d_n_records, uint16_t *d_records);
 
+/* ---- substream assembly on the device --------------
+ * assemble: concatenate the coded substreams in descriptor order into d_payload — the effect of
+ * OutputBitstream::addSubstream (bit_stream.cpp:139-150) on byte-aligned substreams (encode them with
+ * CABAC_SUB_ALIGN_RBSP).  d_offsets receives n_sub + 1 byte offsets (the entry points; the last is the
+ * total).  Bytes beyond payload_capacity are dropped.
+ * split: the inverse (InputBitstream::extractSubstream, bit_stream.cpp:382-415, byte-aligned case):
+ * payload[d_offsets[s] .. d_offsets[s+1]) -> d_bytes + desc[s].byte_offset.
+ * count_emulations: OutputBitstream::countStartCodeEmulations (bit_stream.cpp:157-181) per substream. */
+int cabac_hip_assemble_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                              const cabac_substream_result *d_results, const uint8_t *d_bytes,
+                              uint8_t *d_payload, uint64_t payload_capacity, uint64_t *d_offsets);
+int cabac_hip_split_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                           const uint64_t *d_offsets, const uint8_t *d_payload, uint8_t *d_bytes);
+int cabac_hip_count_emulations_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                      const cabac_substream_result *d_results, const uint8_t *d_bytes,
+                                      uint32_t *d_counts);
+
 /* ---- host-pointer convenience (synchronous; pinned staging inside) --- */
 int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
                            const uint16_t *records, uint64_t n_records_total, uint8_t *bytes,

@@ -809,3 +809,29 @@ void orc_decode_batch(const void *desc_, uint32_t first, uint32_t count, const u
                                     : 0;
   }
 }
+
+/* ---------------------------------------------------------------- start-code emulation count
+ * OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181: greedy scan for
+ * 00 00 {00,01,02,03}; search_n(found, end - 1, 2, 0) keeps the zero pair inside [0, n-1); after a hit the
+ * scan resumes at the third byte. */
+int orc_count_emulations(const uint8_t *p, long n) {
+  int cnt = 0;
+  long it = 0;
+  while (it < n) {
+    long found = it;
+    for (;;) {
+      /* found = search_n(found, end - 1, 2, 0): first q in [found, n-1) with p[q] == p[q+1] == 0 and
+       * q + 1 < n - 1; the end of the range (n - 1) when there is none */
+      long q = found;
+      const long last = n - 1;
+      while (q + 1 < last && !(p[q] == 0 && p[q + 1] == 0)) q++;
+      if (!(q + 1 < last)) q = last;
+      found = q + 1; /* found++ : second zero byte, or end() when not found */
+      if (found == n) break;
+      if (p[++found] <= 3) break; /* third byte */
+    }
+    it = found;
+    if (found != n) cnt++;
+  }
+  return cnt;
+}

@@ -67,6 +67,9 @@ void orc_encode_batch(const void *desc, uint32_t first, uint32_t count, const ui
 void orc_decode_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
                       const uint8_t *bytes, uint8_t *bins, uint32_t *results);
 
+/* OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181 */
+int orc_count_emulations(const uint8_t *bytes, long n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,4 +291,16 @@ int ref_decode_ops(const uint32_t *ops, long n_ops, int qp, int initId, int flag
   }
 }
 
+// OutputBitstream::countStartCodeEmulations on a byte string
+int ref_count_emulations(const uint8_t *bytes, long n) {
+  try {
+    OutputBitstream bs;
+    bs.getFIFO().assign(bytes, bytes + n);
+    return bs.countStartCodeEmulations();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
 } // extern "C"

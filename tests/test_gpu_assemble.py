@@ -1,0 +1,57 @@
+"""GPU: substream assembly / split / start-code-emulation count on the device against
+numpy concatenation and the oracle's restatement of OutputBitstream::countStartCodeEmulations
+(bit_stream.cpp:157-181, pinned to the reference in tests/test_oracle_vs_reference.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers as H
+from entropy_coding_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_assemble_split_count_roundtrip():
+    import torch
+    hip = capi.CabacHip(0)
+    orc = H.load_oracle()
+    orc.lib.orc_count_emulations.argtypes = [H.u8p, ctypes.c_long]
+    rng = np.random.default_rng(12)
+    lens = [1, 2, 17, 500] + [int(x) for x in rng.integers(1, 6000, size=300)]
+    # low-entropy streams (P(1) tiny on one context) give long zero runs -> start-code emulations
+    recs = [H.random_records(rng, n - 1, ctx_frac=1.0, p_one=np.full(379, 0.002), ctx_pool=np.array([7])) if k % 3 == 0
+            else H.random_records(rng, n - 1) for k, n in enumerate(lens)]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc([len(r) for r in recs], rng.integers(0, 64, size=len(recs)), [2] * len(recs),
+                              H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    n = len(desc)
+    t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
+    t_rec = torch.from_numpy(records.view(np.int16)).cuda()
+    t_bytes = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    t_res = torch.zeros(2 * n, dtype=torch.int32, device="cuda")
+    hip.encode_device(n, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res.data_ptr())
+    t_pay = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    t_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    hip.assemble_device(n, t_desc.data_ptr(), t_res.data_ptr(), t_bytes.data_ptr(), t_pay.data_ptr(), total, t_off.data_ptr())
+    t_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hip.count_emulations_device(n, t_desc.data_ptr(), t_res.data_ptr(), t_bytes.data_ptr(), t_cnt.data_ptr())
+    t_back = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    hip.split_device(n, t_desc.data_ptr(), t_off.data_ptr(), t_pay.data_ptr(), t_back.data_ptr())
+    hip.synchronize()
+    res = t_res.cpu().numpy().view(capi.RESULT_DTYPE)
+    out = t_bytes.cpu().numpy()
+    sizes = (res["n_bits"].astype(np.int64) + 7) // 8
+    streams = [out[int(desc["byte_offset"][s]):int(desc["byte_offset"][s]) + int(sizes[s])] for s in range(n)]
+    want = np.concatenate(streams)
+    off = t_off.cpu().numpy()
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(sizes)]))
+    assert np.array_equal(t_pay.cpu().numpy()[: len(want)], want)            # addSubstream order and bytes
+    back = t_back.cpu().numpy()
+    for s in range(n):
+        o = int(desc["byte_offset"][s])
+        assert np.array_equal(back[o:o + int(sizes[s])], streams[s])          # extractSubstream inverse
+    cnt = t_cnt.cpu().numpy()
+    want_cnt = [orc.lib.orc_count_emulations(H._ptr(np.ascontiguousarray(b), H.u8p), len(b)) for b in streams]
+    assert np.array_equal(cnt, np.array(want_cnt, np.int32)) and max(want_cnt) > 0
+    hip.close()

@@ -119,3 +119,17 @@ def test_long_ff_runs_and_carry():
         assert rbits == obits and np.array_equal(rb, ob)
         hits_ff += int((rb == 0xFF).sum() > 8)
     assert hits_ff > 0
+
+
+def test_count_start_code_emulations():
+    import ctypes
+    ref, orc = H.load_ref(), H.load_oracle()
+    ref.lib.ref_count_emulations.argtypes = [H.u8p, ctypes.c_long]
+    orc.lib.orc_count_emulations.argtypes = [H.u8p, ctypes.c_long]
+    rng = np.random.default_rng(31)
+    for trial in range(400):
+        n = int(rng.integers(1, 200))
+        data = rng.choice(np.array([0, 0, 0, 1, 2, 3, 4, 255], np.uint8), size=n)
+        a = ref.lib.ref_count_emulations(H._ptr(data, H.u8p), n)
+        b = orc.lib.orc_count_emulations(H._ptr(data, H.u8p), n)
+        assert a == b, (trial, data.tolist())
