@@ -350,9 +350,13 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   if (kAlign) w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
   // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
   // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
-  const uint32_t s0 = st_v & kMask0, s1 = st_v >> 16;
-  const uint32_t dlt = ((s0 >> r0_v) & kMask0) | (((s1 >> r1_v) & kMask1) << 16);
-  uint32_t upd = st_v - dlt + (a_v & (0u - bin));
+  // both 15-bit estimators at once with packed 16-bit math (v_pk_lshrrev_b16 / v_pk_sub_u16 / v_pk_add_u16):
+  // the halves never borrow or carry into each other, and the rate bits below bit 5 ride along untouched
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 st2 = __builtin_bit_cast(u16x2, st_v);
+  const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, r0_v)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
+  const u16x2 add2 = __builtin_bit_cast(u16x2, a_v & (0u - bin));
+  uint32_t upd = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2 + add2));
   asm volatile("" : "+v"(upd));   // keep the update and the re-derivation below unconditional: hipcc would
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // otherwise wrap them in an exec region (SALU round trip + branch per bin)
@@ -418,8 +422,9 @@ __global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cab
     const bool is_ctx = id < (uint32_t)kNumCtx;
     if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
     uint32_t st_v = is_ctx ? rctx[id] : 0u;
-    const uint32_t r0_v = (st_v & 3u) + 2u, r1_v = ((st_v >> 2) & 7u) + 5u;
-    const uint32_t a_v = ((0x7fffu >> r0_v) & kMask0) | (((0x7fffu >> r1_v) & kMask1) << 16);
+    const uint32_t r0 = (st_v & 3u) + 2u, r1 = ((st_v >> 2) & 7u) + 5u;
+    const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
+    const uint32_t r0_v = r0 | (r1 << 16), r1_v = 0;  // packed shift amounts for the 2 x 16-bit update
     const bool is_trm = active && id == CABAC_REC_TRM;
     const bool is_align = active && id == CABAC_REC_ALIGN;
     QuadDecInfo f;
