@@ -33,12 +33,9 @@ DESC_BYTES, RESULT_BYTES = 32, 8
 
 def kernel_names(enc_variant, dec_variant, n_sub):
     """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
-    def pick(v, auto_v4):
-        kind = v & 0xFF
-        if kind == 4 or (kind == 0 and auto_v4):
-            return "v4"
-        return {1: "v1", 2: "v2"}.get(kind, "v3")
-    return "encode_kernel_" + pick(enc_variant, n_sub > 2048), "decode_kernel_" + pick(dec_variant, True)
+    enc = {1: "v1", 2: "v2", 3: "v3", 4: "v4"}.get(enc_variant & 0xFF, "v5")
+    dec = {1: "v1", 2: "v2", 3: "v3"}.get(dec_variant & 0xFF, "v4")
+    return "encode_kernel_" + enc, "decode_kernel_" + dec
 
 
 def measured_traffic(workload, kernel):

@@ -1156,9 +1156,10 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  // auto (measured): above ~2 048 substreams the quad kernel wins (4 bins per instruction);
-  // below that one wave per substream (v3) has the shorter per-substream chain and keeps more SIMDs busy
-  if (kind == 4 || (kind == 0 && n_sub > 2048u)) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
+  // auto (measured): the two-wave quad encoder (v5) has the shortest per-substream chain at
+  // every batch size tried (C2: 10, C3: 256, C4: 4 096, C5: 8 192 substreams)
+  if (kind == 5 || kind == 0) return launch_encode_v5(st, n_sub, desc, records, bytes, results);
+  if (kind == 4) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
   if (kind == 1) {
     hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
   } else if (kind != 2) {
@@ -1179,7 +1180,7 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
   const int kind = variant & 0xff;
   // auto: the quad decoder has the shortest per-substream chain at every batch size measured (C2: 10,
   // C3: 256, C4: 4 096 substreams), because it never crosses between the scalar and vector pipes
-  if (kind == 4 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results);
+  if (kind == 4 || kind == 5 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results);
   if (kind == 1) {
     hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
   } else if (kind != 2) {

@@ -23,6 +23,8 @@
 //
 // Layout: row r of wave w codes substream 4w + r.  Rows whose substreams are shorter idle at the end,
 // so batches should group substreams of similar length (cabac_hip.h: order is the caller's).
+#include <cstdlib>
+
 #include "cabac_device.h"
 #include "cabac_kernels.h"
 
@@ -160,6 +162,92 @@ __device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e,
   quad_enc_step<15, kAlign>(f, e, writer);
 }
 
+// Phase (a) of one 16-bin step for the four rows: the context state each bin sees, resolved in parallel
+// (see v3), the LDS context store brought up to date, and the bin's chain fields packed into one word:
+//   bits 4..0 k | bits 8..5 2c | bit 9 LPS path | bit 10 bypass | bit 11 bypass bin 1 | bit 12 align
+__device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
+                                                 uint64_t lt_mask, uint32_t &bad) {
+  const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+  const uint32_t bin = (r >> 15) & 1u;
+  const bool is_ctx = id < (uint32_t)kNumCtx;
+  const bool is_ep = active && id == CABAC_REC_EP;
+  const bool is_trm = active && id == CABAC_REC_TRM;
+  const bool is_align = active && id == CABAC_REC_ALIGN;
+  if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+  const uint64_t same = match_any_bits<11>(id | (row << 9));
+  const uint64_t before = same & lt_mask;
+  const uint32_t prev = 63u - (uint32_t)__builtin_clzll(before | 1ull);
+  const bool is_last = (same & ~lt_mask & ~(1ull << lane)) == 0;
+  uint32_t st = is_ctx ? rctx[id] : 0u;
+  bool pending = is_ctx && before != 0;
+  for (;;) {
+    const uint64_t pend = __ballot(pending);
+    if (pend == 0) break;
+    const uint32_t post = ctx2_update(st, bin);
+    const uint32_t pulled = __shfl(post, (int)prev);
+    if (pending && !((pend >> prev) & 1ull)) {  // the previous bin of this context is settled
+      st = pulled;
+      pending = false;
+    }
+  }
+  if (is_ctx && is_last) rctx[id] = ctx2_update(st, bin);
+  const uint32_t q8 = ctx2_q8(st);
+  const uint32_t mps = q8 >> 7;
+  uint32_t info = 0;  // inactive lanes: a no-op step (t = 0, no shift)
+  if (is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) << 9);
+  if (is_trm) info = (4u << 5) | (bin << 9);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
+  if (is_ep) info = (1u << 10) | (bin << 11);
+  if (is_align) info = 1u << 12;
+  return info;
+}
+
+__device__ __forceinline__ QuadEncInfo quad_unpack(uint32_t info) {
+  QuadEncInfo f;
+  f.k = info & 31u;
+  f.c2 = (info >> 5) & 15u;
+  f.lpsm = bit_mask<9>(info);
+  f.ep = (info >> 10) & 1u;
+  f.pem = bit_mask<11>(info);
+  f.alm = bit_mask<12>(info);
+  return f;
+}
+
+// finish(), arith_codec.cpp:339-357, on the exact code value (+ writeByteAlignment, bit_stream.cpp:152-155)
+__device__ __forceinline__ uint32_t quad_enc_finish(QuadEnc &e, bool align_rbsp, bool writer) {
+  const uint32_t total = (uint32_t)(9 + e.pend);
+  if ((e.low >> total) & 1ull) {
+    quad_put16(e, e.buf + 1u, writer);
+    for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0x0000u, writer);
+    e.low -= 1ull << total;
+  } else {
+    if (e.nbuf > 0) quad_put16(e, e.buf, writer);
+    for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0xffffu, writer);
+  }
+  uint32_t nb = (uint32_t)(e.pend + 1);  // write(low >> 8, 24 - bitsLeft)
+  const uint32_t v = (uint32_t)(e.low >> 8);
+  while (nb >= 8) {
+    quad_put_byte(e, (v >> (nb - 8)) & 0xffu, writer);
+    nb -= 8;
+  }
+  uint32_t held = nb ? ((v & ((1u << nb) - 1u)) << (8 - nb)) : 0u;
+  if (align_rbsp) {
+    held |= 1u << (7 - nb);
+    quad_put_byte(e, held, writer);
+    held = 0;
+    nb = 0;
+  }
+  const uint32_t n_bits = e.pos * 8u + nb;
+  if (nb) quad_put_byte(e, held, writer);
+  return n_bits;
+}
+
+__device__ __forceinline__ void quad_ctx_init(uint32_t *rctx, int qp_in, uint32_t iid, uint32_t j) {
+  const int qp = qp_in < 0 ? 0 : (qp_in > 63 ? 63 : qp_in);
+  for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16)
+    rctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+}
+
+// encode, one wave per 4 substreams: phase (a) and the chain alternate in the same wave
 __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                        const uint16_t *__restrict__ records, uint8_t *__restrict__ bytes,
                                                        cabac_substream_result *__restrict__ results) {
@@ -171,12 +259,7 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   const uint32_t n = live ? d.n_records : 0u;
   const uint16_t *rec = records + d.rec_offset;
   uint32_t *rctx = ctx + row * kQuadCtxStride;
-  {
-    const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
-    const uint32_t iid = d.init_id & 3u;
-    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16)
-      rctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
-  }
+  quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
   __syncthreads();
 
   QuadEnc e;
@@ -195,42 +278,8 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   uint32_t next_rec = j < n ? rec[j] : 0;
   for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
     const uint32_t r = next_rec;  // loaded one step ago
-    const bool active = base + j < n;
-    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
-    const uint32_t bin = (r >> 15) & 1u;
-    const bool is_ctx = id < (uint32_t)kNumCtx;
-    const bool is_ep = active && id == CABAC_REC_EP;
-    const bool is_trm = active && id == CABAC_REC_TRM;
-    const bool is_align = active && id == CABAC_REC_ALIGN;
-    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
-
-    // (a) the context state each bin sees — parallel over the 4 x 16 bins (see v3)
-    const uint64_t same = match_any_bits<11>(id | (row << 9));
-    const uint64_t before = same & lt_mask;
-    const uint32_t prev = 63u - (uint32_t)__builtin_clzll(before | 1ull);
-    const bool is_last = (same & ~lt_mask & ~(1ull << lane)) == 0;
-    uint32_t st = is_ctx ? rctx[id] : 0u;
-    bool pending = is_ctx && before != 0;
-    for (;;) {
-      const uint64_t pend = __ballot(pending);
-      if (pend == 0) break;
-      const uint32_t post = ctx2_update(st, bin);
-      const uint32_t pulled = __shfl(post, (int)prev);
-      if (pending && !((pend >> prev) & 1ull)) {
-        st = pulled;
-        pending = false;
-      }
-    }
-    if (is_ctx && is_last) rctx[id] = ctx2_update(st, bin);
-    const uint32_t q8 = ctx2_q8(st);
-    const uint32_t mps = q8 >> 7;
-    QuadEncInfo f;  // inactive lanes: all zero — a no-op step (t = 0, no shift)
-    f.k = is_ctx ? ctx2_k(q8) : 0u;
-    f.c2 = is_ctx ? 8u : (is_trm ? 4u : 0u);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
-    f.lpsm = ((is_ctx && (bin ^ mps)) || (is_trm && bin)) ? ~0u : 0u;
-    f.ep = is_ep ? 1u : 0u;
-    f.pem = (is_ep && bin) ? ~0u : 0u;
-    f.alm = is_align ? ~0u : 0u;
+    const uint32_t info = quad_phase_a(r, base + j < n, lane, row, rctx, lt_mask, bad);
+    const QuadEncInfo f = quad_unpack(info);
     // prefetch the next 16 records of each row now: the load completes under the serial chain.  (Issued
     // any earlier, hipcc's s_waitcnt vmcnt(0) in front of the first use of `r` would wait for it too.)
     {
@@ -238,46 +287,112 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
       next_rec = nxt < n ? rec[nxt] : 0;
     }
     // (b) the serial chain, 4 rows at once
-    if (__ballot(is_align) == 0) quad_enc_steps<false>(f, e, writer);
+    if (__ballot(info >> 12) == 0) quad_enc_steps<false>(f, e, writer);
     else quad_enc_steps<true>(f, e, writer);
   }
 
-  // finish(), arith_codec.cpp:339-357, on the exact code value
-  uint32_t n_bits = 0;
-  if (live) {
-    const uint32_t total = (uint32_t)(9 + e.pend);
-    if ((e.low >> total) & 1ull) {
-      quad_put16(e, e.buf + 1u, writer);
-      for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0x0000u, writer);
-      e.low -= 1ull << total;
-    } else {
-      if (e.nbuf > 0) quad_put16(e, e.buf, writer);
-      for (int32_t k = 1; k < e.nbuf; k++) quad_put16(e, 0xffffu, writer);
-    }
-    uint32_t nb = (uint32_t)(e.pend + 1);  // write(low >> 8, 24 - bitsLeft)
-    const uint32_t v = (uint32_t)(e.low >> 8);
-    while (nb >= 8) {
-      quad_put_byte(e, (v >> (nb - 8)) & 0xffu, writer);
-      nb -= 8;
-    }
-    uint32_t held = nb ? ((v & ((1u << nb) - 1u)) << (8 - nb)) : 0u;
-    if (d.init_id & CABAC_SUB_ALIGN_RBSP) {  // writeByteAlignment, bit_stream.cpp:152-155
-      held |= 1u << (7 - nb);
-      quad_put_byte(e, held, writer);
-      held = 0;
-      nb = 0;
-    }
-    n_bits = e.pos * 8u + nb;
-    if (nb) quad_put_byte(e, held, writer);
-  }
-  // row-wide OR of the bad-record flag
-  const uint64_t bad_mask = __ballot(bad != 0);
+  const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+  const uint64_t bad_mask = __ballot(bad != 0);  // row-wide OR of the bad-record flag
   const bool row_bad = ((bad_mask >> (row * 16u)) & 0xffffull) != 0;
   if (writer) {
     cabac_substream_result res;
     res.n_bits = n_bits;
     res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (row_bad ? CABAC_RES_BAD_RECORD : 0u);
     results[sub] = res;
+  }
+}
+
+// encode, TWO waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead and owns the LDS
+// context stores; a chain wave runs the chain and owns low/range and the output.  The two never wait on
+// each other's memory: the hand-off is one packed word per bin through a double-buffered LDS mailbox and
+// one workgroup barrier per 16-bin step.  A workgroup holds U such pairs (U = 4: eight waves, so that every
+// SIMD of the CU gets one context wave and one chain wave — a workgroup's waves are dealt to the SIMDs
+// cyclically); the context wave's ~250 instructions per step fit into the issue slots the latency-bound
+// chain wave leaves empty.  All pairs of a workgroup run the same number of steps (the longest
+// substream's) so that the barrier counts match; surplus steps are no-ops.
+template <int U>
+__global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                            const uint16_t *__restrict__ records,
+                                                            uint8_t *__restrict__ bytes,
+                                                            cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
+  __shared__ uint32_t mail_all[U][2][64];
+  __shared__ uint32_t bad_rows[U];
+  __shared__ uint32_t wg_max_n;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave
+  const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
+  const bool live = sub < n_sub;
+  const cabac_substream_desc d = desc[live ? sub : 0];
+  const uint32_t n = live ? d.n_records : 0u;
+  uint32_t (*mail)[64] = mail_all[unit];
+
+  if (threadIdx.x == 0) wg_max_n = 0;
+  __syncthreads();
+  atomicMax(&wg_max_n, n);
+  __syncthreads();
+  const uint32_t max_n = wg_max_n;
+
+  if (role == 0) {
+    // ---- context wave ------------------------------------------------------------------------
+    const uint16_t *rec = records + d.rec_offset;
+    uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
+    quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+    uint32_t bad = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t cur_rec = j < n ? rec[j] : 0;
+    uint32_t next_rec = 16u + j < n ? rec[16u + j] : 0;
+    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, lt_mask, bad);  // step 0
+    __syncthreads();
+    uint32_t slot = 1;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      // while the chain wave codes step `base`, prepare step base + 16
+      const uint32_t r = next_rec;
+      {
+        const uint32_t nxt = base + 32u + j;
+        next_rec = nxt < n ? rec[nxt] : 0;
+      }
+      mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
+      slot ^= 1u;
+      __syncthreads();
+    }
+    const uint64_t bad_mask = __ballot(bad != 0);
+    if (lane == 0) {
+      uint32_t rows = 0;
+      for (uint32_t k = 0; k < 4; k++) rows |= ((bad_mask >> (16u * k)) & 0xffffull) ? (1u << k) : 0u;
+      bad_rows[unit] = rows;
+    }
+    __syncthreads();
+  } else {
+    // ---- chain wave --------------------------------------------------------------------------
+    QuadEnc e;
+    e.low = 0;
+    e.range = 510;  // start(), arith_codec.cpp:329-337
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    __syncthreads();
+    uint32_t slot = 0;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      const uint32_t info = mail[slot][lane];
+      slot ^= 1u;
+      const QuadEncInfo f = quad_unpack(info);
+      if (__ballot(info >> 12) == 0) quad_enc_steps<false>(f, e, writer);
+      else quad_enc_steps<true>(f, e, writer);
+      __syncthreads();
+    }
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    __syncthreads();
+    if (writer) {
+      cabac_substream_result res;
+      res.n_bits = n_bits;
+      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
+      results[sub] = res;
+    }
   }
 }
 
@@ -377,13 +492,20 @@ __device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0
 #undef QSTEP
 }
 
-__global__ __launch_bounds__(64) void decode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
-                                                       const uint16_t *__restrict__ records,
-                                                       const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
-                                                       cabac_substream_result *__restrict__ results) {
-  __shared__ uint32_t ctx[kQuadSubs * kQuadCtxStride];
-  const uint32_t lane = threadIdx.x, row = lane >> 4, j = lane & 15u;
-  const uint32_t sub = blockIdx.x * kQuadSubs + row;
+// W independent waves per workgroup: with W = 4 a workgroup's waves are dealt to the CU's four SIMDs, which
+// pins "one chain wave per SIMD" instead of leaving it to where the dispatcher happens to put
+// single-wave workgroups (measured: the same decode kernel ran 2.06 ms or 3.3 ms depending on the geometry
+// of the kernel launched before it).
+template <int W>
+__global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                           const uint16_t *__restrict__ records,
+                                                           const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
+                                                           cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
+  const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+  const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
   const uint32_t n = live ? d.n_records : 0u;
@@ -485,10 +607,29 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
   return hipGetLastError();
 }
 
+hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint8_t *bytes, cabac_substream_result *results) {
+  const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
+  static int upw = -1;  // pairs per workgroup; CABAC_V5_UNITS overrides for experiments
+  if (upw < 0) {
+    const char *e = getenv("CABAC_V5_UNITS");
+    upw = e ? atoi(e) : 1;
+  }
+  if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(512), 0, st, n_sub, desc, records, bytes, results);
+  else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(256), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(128), 0, st, n_sub, desc, records, bytes, results);
+  return hipGetLastError();
+}
+
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results) {
-  hipLaunchKernelGGL(decode_kernel_v4, dim3((n_sub + kQuadSubs - 1) / kQuadSubs), dim3(64), 0, st, n_sub, desc, records,
-                     bytes, bins, results);
+  const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
+  if (waves >= 1024u) {
+    hipLaunchKernelGGL(decode_kernel_v4<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, bytes, bins,
+                       results);
+  } else {
+    hipLaunchKernelGGL(decode_kernel_v4<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
+  }
   return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # kernel variants: 0 = auto, 1 = v1 wave-serial, 2 | L << 8 = v2 lane-per-substream with L lanes per wave
-VARIANTS = {"auto": 0, "v1": 1, "v2_L4": 2 | (4 << 8), "v3": 3, "v4": 4}
+VARIANTS = {"auto": 0, "v1": 1, "v2_L4": 2 | (4 << 8), "v3": 3, "v4": 4, "v5": 5}
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
