@@ -365,6 +365,9 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     __syncthreads();
   } else {
     // ---- chain wave --------------------------------------------------------------------------
+    // the chain is the critical path: let it win issue arbitration against the context wave that shares its
+    // SIMD (the context wave then only fills the slots the chain's dependencies leave empty)
+    __builtin_amdgcn_s_setprio(3);
     QuadEnc e;
     e.low = 0;
     e.range = 510;  // start(), arith_codec.cpp:329-337
