@@ -130,9 +130,12 @@ __device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, 
   const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23);  // getRenormBitsLPS (contexts.cpp:952-954); masked out when t == 0
   const uint32_t nm = (rm >> 8) ^ 1u;                     // rm < 512: 1 iff rm < 256
   const uint32_t nb = sel(lpsm, nl, nm);
-  e.low = (e.low + (rm & lpsm)) << nb;
   e.range = sel(lpsm, t, rm) << nb;
-  e.low = (e.low << ep) + (e.range & row_bcast<I>(f.pem));  // encodeBinEP (arith_codec.cpp:389-399)
+  // low = ((low + (LPS ? rm : 0)) << nb), then for a bypass bin (low << 1) + bin * range (arith_codec.cpp:389-399,
+  // :553-582).  The two additions exclude each other, so both go after ONE shift: a single 64-bit shift and
+  // add per bin keep the 64-bit dependency chain short.
+  const uint32_t term = ((rm & lpsm) << nb) | (e.range & row_bcast<I>(f.pem));
+  e.low = (e.low << (nb + ep)) + term;
   if (kAlign) e.range = sel(row_bcast<I>(f.alm), 256u, e.range);
   e.pend += (int32_t)(nb + ep);
   // output check only every 4th bin: 4 bins shift at most 28 bits, which the 64-bit low absorbs, and the
