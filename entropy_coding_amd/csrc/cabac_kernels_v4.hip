@@ -65,7 +65,6 @@ __device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { re
 struct QuadEnc {       // row-uniform values
   uint64_t low;        // exact code value: 9 + pend (+1 carry) bits; pend <= 15 + 4*7 between flush checks
   uint32_t range;
-  uint32_t nbp, xp, epp, pmp;  // what the previous bin still owes low / pend (see quad_enc_step)
   int32_t pend;        // bits shifted since the last 16-bit unit was peeled off (< 16 between steps)
   uint32_t buf;        // buffered unit
   int32_t nbuf;        // buffered unit + outstanding 0xFFFF units
@@ -123,165 +122,31 @@ struct QuadEncInfo {
 // One chain step for the four rows.  The fields reach the row by DPP row broadcasts; masks are used
 // with and/bfi (no compares, no exec regions): the wave is alone on its SIMD and every VALU->SALU->EXEC
 // round trip would sit on the critical path.
-//
-// Scheduling.  Measured on gfx950 (tools/ubench_lat.hip): a wave issues one vector instruction per 4 cycles
-// but a DEPENDENT one only 9 cycles after its producer, and a lone wave issues strictly in program order.
-// The range recurrence is 8 dependent instructions deep, so left to hipcc (which emits them back to back)
-// a step takes ~146 cycles for 23 instructions.  The step is therefore software-pipelined by hand: the
-// `low` / `pend` update of the PREVIOUS bin and the DPP loads are placed between the
-// dependent range instructions, and the order is pinned with volatile asm (sched_barrier does not hold it).
-// PIN / PIN2: an empty volatile asm that "rewrites" its operands.  Volatile asms keep their program order, so
-// an operation whose result is pinned right after it, and one of whose inputs was pinned two operations
-// earlier, stays where it is written (to within a swap with its neighbour).  An input is never pinned
-// directly in front of its use: hipcc assumes a forwarding hazard after any asm definition and would pad
-// with s_nop, which costs a full issue slot.
-#define PIN(x) asm volatile("" : "+v"(x))
-#define PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
-template <int I>
-__device__ __forceinline__ uint32_t row_bcast_pinned(uint32_t v) {
-  uint32_t r;  // the source must not have been written by the two preceding VALU instructions (DPP hazard)
-  asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "n"(I));
-  return r;
-}
-
 template <int I, bool kAlign>
 __device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, bool writer) {
-  // c* = the range recurrence of THIS bin (8 dependent instructions); d* = the update of low / pend owed
-  // by the PREVIOUS bin, from the values it left in nbp / xp / epp / pmp.  Two independent instructions
-  // between dependent ones hide the 9-cycle latency.
-  const uint32_t k = row_bcast_pinned<I>(f.k);
-  const uint32_t c2 = row_bcast_pinned<I>(f.c2);
-  uint32_t r5 = e.range >> 5;                                // c1
-  PIN2(r5, e.xp);
-  uint32_t sh = e.nbp + e.epp;                               // d1
-  PIN2(sh, r5);
-  uint32_t xs = e.xp << e.nbp;                               // d2
-  PIN2(xs, sh);
-  uint32_t m = __umul24(r5, k) + c2;                         // c2: LPS width t = ((r>>5)*k + 2c) >> 1
-  PIN(m);
-  uint32_t pm = row_bcast_pinned<I>(f.pem);
-  e.low <<= sh;                                              // d3
-  PIN2(e.low, xs);
-  uint32_t t = m >> 1;                                       // c3
-  PIN(t);
+  const uint32_t k = row_bcast<I>(f.k), c2 = row_bcast<I>(f.c2), lpsm = row_bcast<I>(f.lpsm), ep = row_bcast<I>(f.ep);
+  const uint32_t t = (__umul24((e.range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+  const uint32_t rm = e.range - t;
+  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23);  // getRenormBitsLPS (contexts.cpp:952-954); masked out when t == 0
+  const uint32_t nm = (rm >> 8) ^ 1u;                     // rm < 512: 1 iff rm < 256
+  const uint32_t nb = sel(lpsm, nl, nm);
+  e.range = sel(lpsm, t, rm) << nb;
   // low = ((low + (LPS ? rm : 0)) << nb), then for a bypass bin (low << 1) + bin * range (arith_codec.cpp:389-399,
-  // :553-582).  The two additions exclude each other, so both go after ONE shift.
-  uint32_t term = (e.range & e.pmp) | xs;                    // d4 (range still is the previous bin's result)
-  PIN2(term, t);
-  uint32_t lpsm = row_bcast_pinned<I>(f.lpsm);
-  uint32_t rm = e.range - t;                                 // c4
-  PIN2(rm, sh);
-  uint32_t h = (uint32_t)__builtin_clz(t);                   // getRenormBitsLPS (contexts.cpp:952-954); masked out when t == 0
-  PIN2(h, rm);
-  e.pend += (int32_t)sh;                                     // d5
-  PIN2(e.pend, h);
-  uint32_t q = rm >> 8;                                      // c5
-  PIN2(q, rm);
-  uint32_t nl = h - 23u;
-  PIN2(nl, q);
-  uint32_t x = rm & lpsm;
-  PIN2(x, rm);
-  uint32_t nm = q ^ 1u;                                      // c6: rm < 512, so 1 iff rm < 256
-  PIN2(nm, term);
-  uint32_t base = sel(lpsm, t, rm);
-  PIN2(base, nm);
-  e.low += term;                                             // d6
-  PIN(e.low);
-  uint32_t nb = sel(lpsm, nl, nm);                           // c7
-  PIN2(nb, base);
-  uint32_t ep = row_bcast_pinned<I>(f.ep);
-  e.range = base << nb;                                      // c8
-  PIN(e.range);
+  // :553-582).  The two additions exclude each other, so both go after ONE shift: a single 64-bit shift and
+  // add per bin keep the 64-bit dependency chain short.
+  const uint32_t term = ((rm & lpsm) << nb) | (e.range & row_bcast<I>(f.pem));
+  e.low = (e.low << (nb + ep)) + term;
   if (kAlign) e.range = sel(row_bcast<I>(f.alm), 256u, e.range);
-  e.nbp = nb;
-  e.xp = x;
-  e.epp = ep;
-  e.pmp = pm;
-  // Output check only every 4th bin (low / pend are current up to bin I-1 here): 4 bins shift at most 28 bits,
-  // which the 64-bit low absorbs, and the steps in between stay in one basic block.
-  if ((I & 3) == 0) {
+  e.pend += (int32_t)(nb + ep);
+  // output check only every 4th bin: 4 bins shift at most 28 bits, which the 64-bit low absorbs, and the
+  // three steps in between stay in one basic block, so hipcc can overlap their independent parts
+  if ((I & 3) == 3) {
     while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
   }
 }
-#undef PIN
-#undef PIN2
-
-// apply the update the last bin still owes (before finish)
-__device__ __forceinline__ void quad_enc_drain(QuadEnc &e, bool writer) {
-  const uint32_t sh = e.nbp + e.epp;
-  e.low = (e.low << sh) + ((e.range & e.pmp) | (e.xp << e.nbp));
-  e.pend += (int32_t)sh;
-  e.nbp = e.xp = e.epp = e.pmp = 0;
-  while (e.pend >= 16) quad_flush16(e, writer);
-}
-
-// Four chain steps (bins I0 .. I0+3) as ONE hand-scheduled asm block, for groups without align records.
-// Same arithmetic as quad_enc_step<I, false>, but the order is exact: every dependent pair has two
-// independent instructions between it, the next bin's k / 2c broadcasts fill the gap in front of the last
-// range instruction, and hipcc cannot pad between the instructions (between separate asm statements it
-// assumes a forwarding hazard and inserts s_nop).  v[62:63] carries the 64-bit addend {term, 0}.
-#define QE_DPP(dst, src, idx) "v_mov_b32_dpp " dst ", " src " row_newbcast:" idx " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define QE_STEP(idx, tail)                                                                  \
-  "v_add_u32 %[sh], %[nb], %[ep]\n\t"              /* d1: shift owed by the previous bin */ \
-  "v_lshrrev_b32 %[a], 5, %[r]\n\t"                /* c1 */                                 \
-  "v_lshlrev_b32 %[xs], %[nb], %[xp]\n\t"          /* d2 */                                 \
-  "v_lshlrev_b64 %[lo], %[sh], %[lo]\n\t"          /* d3 */                                 \
-  "v_mad_u32_u24 %[a], %[a], %[k], %[c]\n\t"       /* c2 */                                 \
-  QE_DPP("%[lm]", "%[flps]", idx)                                                           \
-  "v_and_or_b32 v62, %[r], %[pm], %[xs]\n\t"       /* d4: term */                           \
-  "v_lshrrev_b32 %[a], 1, %[a]\n\t"                /* c3: t */                              \
-  QE_DPP("%[pm]", "%[fpem]", idx)                                                           \
-  "v_add_u32 %[pend], %[pend], %[sh]\n\t"          /* d5 */                                 \
-  "v_sub_u32 %[rm], %[r], %[a]\n\t"                /* c4 */                                 \
-  "v_ffbh_u32 %[h], %[a]\n\t"                                                               \
-  "v_lshl_add_u64 %[lo], %[lo], 0, v[62:63]\n\t"   /* d6 */                                 \
-  "v_lshrrev_b32 %[q], 8, %[rm]\n\t"               /* c5 */                                 \
-  "v_subrev_u32 %[h], 23, %[h]\n\t"                /* nl */                                 \
-  "v_and_b32 %[xp], %[rm], %[lm]\n\t"              /* x, owed to the next bin */            \
-  "v_xor_b32 %[q], 1, %[q]\n\t"                    /* c6: nm */                             \
-  "v_bfi_b32 %[b], %[lm], %[a], %[rm]\n\t"         /* base */                               \
-  QE_DPP("%[ep]", "%[fep]", idx)                                                            \
-  "v_bfi_b32 %[nb], %[lm], %[h], %[q]\n\t"         /* c7 */                                 \
-  tail                                                                                      \
-  "v_lshlrev_b32 %[r], %[nb], %[b]\n\t"            /* c8 */
-#define QE_NEXT(idx) QE_DPP("%[k]", "%[fk]", idx) QE_DPP("%[c]", "%[fc2]", idx)
-template <int I0>
-__device__ __forceinline__ void quad_enc_block4(const QuadEncInfo &f, QuadEnc &e) {
-  uint32_t a, sh, xs, k, c, lm, rm, h, q, b;
-  asm volatile(
-      "s_nop 0\n\t"  // with the v_mov: two wait states between a VALU write of the fields and the DPP reads
-      "v_mov_b32 v63, 0\n\t"
-      QE_NEXT("%[i0]")
-      QE_STEP("%[i0]", QE_NEXT("%[i1]"))
-      QE_STEP("%[i1]", QE_NEXT("%[i2]"))
-      QE_STEP("%[i2]", QE_NEXT("%[i3]"))
-      QE_STEP("%[i3]", "")
-      : [r] "+v"(e.range), [lo] "+v"(e.low), [pend] "+v"(e.pend), [nb] "+v"(e.nbp), [xp] "+v"(e.xp), [ep] "+v"(e.epp),
-        [pm] "+v"(e.pmp), [a] "=&v"(a), [sh] "=&v"(sh), [xs] "=&v"(xs), [k] "=&v"(k), [c] "=&v"(c), [lm] "=&v"(lm),
-        [rm] "=&v"(rm), [h] "=&v"(h), [q] "=&v"(q), [b] "=&v"(b)
-      : [fk] "v"(f.k), [fc2] "v"(f.c2), [flps] "v"(f.lpsm), [fep] "v"(f.ep), [fpem] "v"(f.pem), [i0] "n"(I0),
-        [i1] "n"(I0 + 1), [i2] "n"(I0 + 2), [i3] "n"(I0 + 3)
-      : "v62", "v63");
-}
-#undef QE_NEXT
-#undef QE_STEP
-#undef QE_DPP
 
 template <bool kAlign>
 __device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e, bool writer) {
-  if (!kAlign) {
-    // low / pend are current up to the bin before the last one after each block: 4 bins shift at most 28 bits
-    quad_enc_block4<0>(f, e);
-    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
-    quad_enc_block4<4>(f, e);
-    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
-    quad_enc_block4<8>(f, e);
-    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
-    quad_enc_block4<12>(f, e);
-    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
-    return;
-  }
-  asm volatile("s_nop 1");  // the fields were just written: DPP reads need two wait states after a VALU write
   quad_enc_step<0, kAlign>(f, e, writer);
   quad_enc_step<1, kAlign>(f, e, writer);
   quad_enc_step<2, kAlign>(f, e, writer);
@@ -352,7 +217,6 @@ __device__ __forceinline__ QuadEncInfo quad_unpack(uint32_t info) {
 
 // finish(), arith_codec.cpp:339-357, on the exact code value (+ writeByteAlignment, bit_stream.cpp:152-155)
 __device__ __forceinline__ uint32_t quad_enc_finish(QuadEnc &e, bool align_rbsp, bool writer) {
-  quad_enc_drain(e, writer);
   const uint32_t total = (uint32_t)(9 + e.pend);
   if ((e.low >> total) & 1ull) {
     quad_put16(e, e.buf + 1u, writer);
@@ -405,7 +269,6 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   e.low = 0;
   e.range = 510;  // start(), arith_codec.cpp:329-337
   e.pend = 0;
-  e.nbp = e.xp = e.epp = e.pmp = 0;
   e.buf = 0;
   e.nbuf = 0;
   e.pos = 0;
@@ -512,7 +375,6 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     e.low = 0;
     e.range = 510;  // start(), arith_codec.cpp:329-337
     e.pend = 0;
-    e.nbp = e.xp = e.epp = e.pmp = 0;
     e.buf = 0;
     e.nbuf = 0;
     e.pos = 0;

@@ -8,7 +8,7 @@ using namespace cabac;
 __global__ void chain_bench(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed, uint8_t *scratch) {
   const uint32_t lane = threadIdx.x & 63u;
   QuadEnc e;
-  e.low = 0; e.range = 510; e.pend = 0; e.nbp = e.xp = e.epp = e.pmp = 0; e.buf = 0; e.nbuf = 0; e.pos = 0; e.dst = scratch + (blockIdx.x * 4 + (lane >> 4)) * 65536; e.cap = 65536;
+  e.low = 0; e.range = 510; e.pend = 0; e.buf = 0; e.nbuf = 0; e.pos = 0; e.dst = scratch + (blockIdx.x * 4 + (lane >> 4)) * 65536; e.cap = 65536;
   uint32_t x = seed * 2654435761u + lane * 40503u + blockIdx.x * 977u;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it++) {
