@@ -414,25 +414,31 @@ struct QuadDec {   // row-uniform values
   uint32_t cap;
 };
 
-// Per-lane fields of one record for the decode chain
+// Per-lane fields of one record for the decode chain.  A lane past the end of its substream carries the
+// fields of "nothing" (c2 = 0, ep = 0, ctxm = 0): t = 0, value < range keeps the comparison false, and the
+// step changes nothing.
 struct QuadDecInfo {
   uint32_t c2;    // 2 * constant term of the LPS width: 8 context bin, 4 terminate bin, 0 bypass / none
   uint32_t ep;    // 1 for a bypass bin
+  uint32_t srmul; // 2^(22 - ep): the bypass doubling of value (arith_codec.cpp:100-105) is done by comparing against
+                  // scaledRange / 2 and shifting afterwards, together with the renormalisation
   uint32_t ctxm;  // ~0 for a context-coded bin
-  uint32_t ntrm;  // 0 for a terminate bin, ~0 otherwise
-  uint32_t actm;  // ~0 for a real record, 0 past the end of the substream (the step changes nothing)
-  uint32_t alm;   // ~0 for an align() record
-  uint32_t key;   // ctxId of a context bin; 0xfff otherwise
+  uint32_t ntrm;  // 0 for a terminate bin, ~0 otherwise            (kSpecial steps only)
+  uint32_t alm;   // ~0 for an align() record                        (kSpecial steps only)
+  uint32_t key;   // ctxId of a context bin; a value unique in the row otherwise (so that it matches no other lane)
 };
 
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
-// every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip, and
-// this chain is latency bound.  Per-lane state: st_v (packed context word of the lane's own record),
-// k_v / mps_v derived from it.
-template <int I, bool kAlign>
-__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_v, uint32_t r1_v, uint32_t a_v,
-                                              uint32_t &st_v, uint32_t &k_v, uint32_t &mps_v, uint32_t &my_bin,
-                                              uint32_t j, QuadDec &w) {
+// every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip.  The cost
+// of a step is its instruction count: a wave issues one instruction per ~4.4 cycles whether or not it
+// depends on the previous one (tools/ubench_ilp.hip), so nothing is gained by shortening dependency
+// chains and everything by dropping instructions.
+// Per-lane state: st_v, the packed context word of the lane's own record (0 for a non-context record).
+// kSpecial: the 16 records contain a terminate or an align record (rare) — the common variant leaves their
+// handling out.
+template <int I, bool kSpecial>
+__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+                                              uint32_t &bits, QuadDec &w) {
   // input check only every 4th bin (4 bins consume at most 28 bits): 16-bit units are appended while fewer
   // than 32 look-ahead bits are valid, so that the three steps in between stay in one basic block
   if ((I & 3) == 0) {
@@ -446,53 +452,60 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
       if ((w.rp & 2u) == 0u) w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
     }
   }
-  const uint32_t k = row_bcast<I>(k_v), c2 = row_bcast<I>(f.c2), ep = row_bcast<I>(f.ep);
-  {  // decodeBinEP doubles value before comparing (arith_codec.cpp:100-105)
-    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << ep;
-    w.hi = (uint32_t)(v >> 32);
-    w.lo = (uint32_t)v;
-  }
-  const uint32_t t = (__umul24((w.range >> 5) & 15u, k) + c2) >> 1;
+  // the state of this bin's context, from the lane that holds the record; state() / getLPS, contexts.cpp:939-950
+  const uint32_t st = row_bcast<I>(st_v);
+  const uint32_t sum = (st & kMask0) + (st >> 16);
+  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
+  const uint32_t k = ((sum >> 10) ^ sx) & 31u;
+  const uint32_t mps = sum >> 15;                                // 0 for a non-context record (st == 0)
+  const uint32_t t = (__umul24(w.range >> 5, k) + row_bcast<I>(f.c2)) >> 1;
   const uint32_t rm = w.range - t;
-  const uint32_t sr = rm << 22;
-  const uint32_t gem = (w.hi >= sr ? ~0u : 0u) & row_bcast<I>(f.actm);  // value >= scaledRange (LPS / bin 1)
-  const uint32_t bin = (gem & 1u) ^ row_bcast<I>(mps_v);                 // mps == 0 for non-context records
-  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23) & row_bcast<I>(f.ctxm);
-  const uint32_t nm = ((rm >> 8) ^ 1u) & row_bcast<I>(f.actm);            // rm < 512: 1 iff rm < 256
-  const uint32_t nsh = sel(gem, nl, nm);
-  w.hi -= (sr & gem) & row_bcast<I>(f.ntrm);                              // terminate bin 1 leaves value untouched (:184-185)
-  w.range = sel(gem & row_bcast<I>(f.ctxm), t, rm) << nsh;
+  // scaledRange at the window's scale, 2^22 (2^21 for a bypass bin) * rm.  As a multiplication on purpose: hipcc
+  // folds the broadcast into the consumer, and v_lshlrev_b32 with DPP on its shift-amount operand returned
+  // wrong results on gfx950 (bisected with the parity tests); v_mul_u32_u24 with DPP is fine.
+  const uint32_t sr = __umul24(rm, row_bcast<I>(f.srmul));
+  const uint32_t e = w.hi - sr;                                  // value - scaledRange; both are below 2^31
+  const uint32_t ngem = (uint32_t)((int32_t)e >> 31);            // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0
+  const uint32_t bin = (~ngem ^ mps) & 1u;
+  const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
+  const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;          // getRenormBitsLPS; masked out when t == 0
+  const uint32_t nsh = (gc & nl) | (((rm >> 8) ^ 1u) & ngem);    // MPS path: rm < 512, so 1 iff rm < 256
+  uint32_t keep = ngem;
+  if (kSpecial) keep |= ~row_bcast<I>(f.ntrm);                   // terminate bin 1 leaves value untouched (:184-185)
+  w.hi = sel(keep, w.hi, e);
+  w.range = sel(gc, t, rm) << nsh;
+  if (kSpecial) {
+    w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
+    // After a terminate bin 1 nothing but finish() follows; keep range >= 256 so that the no-op steps past the
+    // end of the substream (t = 0, rm = range) never look like a renormalising MPS step.
+    w.range |= 256u & ~(ngem | row_bcast<I>(f.ntrm));
+  }
   {
-    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << nsh;
+    const uint32_t tot = nsh + row_bcast<I>(f.ep);
+    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
+    w.look -= (int32_t)tot;
   }
-  w.look -= (int32_t)(nsh + ep);
-  if (kAlign) w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
+  bits |= bin << I;
   // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
-  // same ctxId keep it (update(), contexts.cpp:903-913) and re-derive their LPS factor
-  // both 15-bit estimators at once with packed 16-bit math (v_pk_lshrrev_b16 / v_pk_sub_u16 / v_pk_add_u16):
-  // the halves never borrow or carry into each other, and the rate bits below bit 5 ride along untouched
+  // same ctxId keep it (update(), contexts.cpp:903-913).
+  // Both 15-bit estimators at once with packed 16-bit math: the halves never borrow or carry into each
+  // other, and the rate bits below bit 5 ride along untouched.
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   const u16x2 st2 = __builtin_bit_cast(u16x2, st_v);
   const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, r0_v)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
-  const u16x2 add2 = __builtin_bit_cast(u16x2, a_v & (0u - bin));
-  uint32_t upd = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2 + add2));
-  asm volatile("" : "+v"(upd));   // keep the update and the re-derivation below unconditional: hipcc would
+  const u16x2 bin2 = __builtin_bit_cast(u16x2, bin | (bin << 16));
+  uint32_t upd = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a_v) * bin2 + (st2 - dlt2)));
+  asm volatile("" : "+v"(upd));   // keep the update unconditional: hipcc would otherwise wrap it in an exec
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
-  asm volatile("" : "+v"(st_v));  // otherwise wrap them in an exec region (SALU round trip + branch per bin)
-  const uint32_t sum = (st_v & kMask0) + (st_v >> 16);           // state(), contexts.cpp:939-941
-  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);     // 0 / ~0 from the MPS bit (bit 15)
-  k_v = (((sum >> 10) ^ sx) & 31u) & f.ctxm;
-  mps_v = (sum >> 15) & f.ctxm & 1u;
-  my_bin = (j == (uint32_t)I) ? bin : my_bin;
+  asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
 }
 
-template <bool kAlign>
-__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0_v, uint32_t r1_v, uint32_t a_v,
-                                               uint32_t &st_v, uint32_t &k_v, uint32_t &mps_v, uint32_t &my_bin,
-                                               uint32_t j, QuadDec &w) {
-#define QSTEP(I) quad_dec_step<I, kAlign>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w)
+template <bool kSpecial>
+__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+                                               uint32_t &bits, QuadDec &w) {
+#define QSTEP(I) quad_dec_step<I, kSpecial>(f, r0_v, a_v, st_v, bits, w)
   QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
   QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
 #undef QSTEP
@@ -552,31 +565,26 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     uint32_t st_v = is_ctx ? rctx[id] : 0u;
     const uint32_t r0 = (st_v & 3u) + 2u, r1 = ((st_v >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
-    const uint32_t r0_v = r0 | (r1 << 16), r1_v = 0;  // packed shift amounts for the 2 x 16-bit update
+    const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
     const bool is_trm = active && id == CABAC_REC_TRM;
     const bool is_align = active && id == CABAC_REC_ALIGN;
     QuadDecInfo f;
     f.c2 = is_ctx ? 8u : (is_trm ? 4u : 0u);
     f.ep = (active && id == CABAC_REC_EP) ? 1u : 0u;
+    f.srmul = 1u << (22u - f.ep);
     f.ctxm = is_ctx ? ~0u : 0u;
     f.ntrm = is_trm ? 0u : ~0u;
-    f.actm = active ? ~0u : 0u;
     f.alm = is_align ? ~0u : 0u;
-    f.key = is_ctx ? id : 0xfffu;
-    uint32_t k_v, mps_v;
-    {
-      const uint32_t q8 = ctx2_q8(st_v);
-      k_v = is_ctx ? ctx2_k(q8) : 0u;
-      mps_v = is_ctx ? (q8 >> 7) : 0u;
-    }
-    const bool any_align = __ballot(is_align) != 0;
+    f.key = is_ctx ? id : (0x200u + j);
+    const bool any_special = __ballot(is_align || is_trm) != 0;
     {  // prefetch the next step's records (see encode)
       const uint32_t nxt = base + 16u + j;
       next_rec = nxt < n ? rec[nxt] : 0;
     }
-    uint32_t my_bin = 0;
-    if (!any_align) quad_dec_steps<false>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w);
-    else quad_dec_steps<true>(f, r0_v, r1_v, a_v, st_v, k_v, mps_v, my_bin, j, w);
+    uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
+    if (!any_special) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
+    else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
+    const uint32_t my_bin = (bits >> j) & 1u;
     if (is_ctx) rctx[id] = st_v;
     if (active) out[base + j] = (uint8_t)my_bin;
   }

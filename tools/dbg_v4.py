@@ -19,3 +19,12 @@ for s in range(len(lens)):
         bad = np.nonzero(bins_g[o:o+n]!=bins_o[o:o+n])[0]
         r = records[o:o+n]
         print(s, n, "flags", res_g["flags"][s], "nbits", res_g["n_bits"][s], res_o["n_bits"][s], "cap", ddesc["byte_capacity"][s], "first bad", bad[:3], [hex(x) for x in r[bad[:1]]] if len(bad) else "")
+for s in (10, 11, 34):
+    o=int(desc["rec_offset"][s]); n=lens[s]
+    bad = np.nonzero(bins_g[o:o+n]!=bins_o[o:o+n])[0]
+    print("sub", s, "bad positions", bad.tolist()[:20])
+    for b in bad[:3]:
+        g0 = (b//16)*16
+        print("  group", g0, [hex(int(x)) for x in records[o+g0:o+g0+16]])
+        print("  got ", bins_g[o+g0:o+g0+16].tolist())
+        print("  want", bins_o[o+g0:o+g0+16].tolist())
