@@ -109,6 +109,14 @@ __device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
   }
 }
 
+// Where the chain wave of the two-wave encoder (v5) leaves its output: every 4th bin it posts (low, pend) to LDS
+// and keeps only the pend % 16 bits that are not yet a whole unit; the context wave peels the units off the
+// posted value one step later (quad_flush16) — the carry / output stage is serial per unit and full of
+// per-row conditions, and on the chain wave it cost 30 % of the kernel.
+struct QuadPost {
+  uint32_t *lo, *hi, *pend;  // [check 0..3][row 0..3] of the current step's slot, already offset to this row
+};
+
 // Per-lane fields of one bin for the chain (phase A fills them; all zero = no-op step)
 struct QuadEncInfo {
   uint32_t k;     // LPS factor (state folded to 0..127) >> 2; 0 for bypass / terminate
@@ -122,8 +130,8 @@ struct QuadEncInfo {
 // One chain step for the four rows.  The fields reach the row by DPP row broadcasts; masks are used
 // with and/bfi (no compares, no exec regions): the wave is alone on its SIMD and every VALU->SALU->EXEC
 // round trip would sit on the critical path.
-template <int I, bool kAlign>
-__device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, bool writer) {
+template <int I, bool kAlign, bool kPost>
+__device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, bool writer, const QuadPost &post) {
   const uint32_t k = row_bcast<I>(f.k), c2 = row_bcast<I>(f.c2), lpsm = row_bcast<I>(f.lpsm), ep = row_bcast<I>(f.ep);
   const uint32_t t = (__umul24((e.range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
   const uint32_t rm = e.range - t;
@@ -141,28 +149,31 @@ __device__ __forceinline__ void quad_enc_step(const QuadEncInfo &f, QuadEnc &e, 
   // output check only every 4th bin: 4 bins shift at most 28 bits, which the 64-bit low absorbs, and the
   // three steps in between stay in one basic block, so hipcc can overlap their independent parts
   if ((I & 3) == 3) {
-    while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
+    if (kPost) {
+      constexpr int kCheck = (I >> 2) * kQuadSubs;
+      if (writer) {
+        post.lo[kCheck] = (uint32_t)e.low;
+        post.hi[kCheck] = (uint32_t)(e.low >> 32);
+        post.pend[kCheck] = (uint32_t)e.pend;
+      }
+      // whole units, and the carry above them, now belong to the post; without a whole unit nothing is cut
+      // (a carry bit above the 9 + pend bits must stay until it can be posted on top of a unit)
+      const uint32_t keep = (uint32_t)e.pend & 15u;
+      const uint32_t width = e.pend >= 16 ? 9u + keep : 63u;
+      e.low &= ~(~0ull << width);
+      e.pend = (int32_t)keep;
+    } else {
+      while (__builtin_expect(e.pend >= 16, 0)) quad_flush16(e, writer);
+    }
   }
 }
 
-template <bool kAlign>
-__device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e, bool writer) {
-  quad_enc_step<0, kAlign>(f, e, writer);
-  quad_enc_step<1, kAlign>(f, e, writer);
-  quad_enc_step<2, kAlign>(f, e, writer);
-  quad_enc_step<3, kAlign>(f, e, writer);
-  quad_enc_step<4, kAlign>(f, e, writer);
-  quad_enc_step<5, kAlign>(f, e, writer);
-  quad_enc_step<6, kAlign>(f, e, writer);
-  quad_enc_step<7, kAlign>(f, e, writer);
-  quad_enc_step<8, kAlign>(f, e, writer);
-  quad_enc_step<9, kAlign>(f, e, writer);
-  quad_enc_step<10, kAlign>(f, e, writer);
-  quad_enc_step<11, kAlign>(f, e, writer);
-  quad_enc_step<12, kAlign>(f, e, writer);
-  quad_enc_step<13, kAlign>(f, e, writer);
-  quad_enc_step<14, kAlign>(f, e, writer);
-  quad_enc_step<15, kAlign>(f, e, writer);
+template <bool kAlign, bool kPost>
+__device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e, bool writer, const QuadPost &post) {
+#define QSTEP(I) quad_enc_step<I, kAlign, kPost>(f, e, writer, post)
+  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
+  QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+#undef QSTEP
 }
 
 // Phase (a) of one 16-bin step for the four rows: the context state each bin sees, resolved in parallel
@@ -290,8 +301,8 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
       next_rec = nxt < n ? rec[nxt] : 0;
     }
     // (b) the serial chain, 4 rows at once
-    if (__ballot(info >> 12) == 0) quad_enc_steps<false>(f, e, writer);
-    else quad_enc_steps<true>(f, e, writer);
+    if (__ballot(info >> 12) == 0) quad_enc_steps<false, false>(f, e, writer, QuadPost());
+    else quad_enc_steps<true, false>(f, e, writer, QuadPost());
   }
 
   const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
@@ -305,14 +316,76 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   }
 }
 
-// encode, TWO waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead and owns the LDS
-// context stores; a chain wave runs the chain and owns low/range and the output.  The two never wait on
-// each other's memory: the hand-off is one packed word per bin through a double-buffered LDS mailbox and
-// one workgroup barrier per 16-bin step.  A workgroup holds U such pairs (U = 4: eight waves, so that every
-// SIMD of the CU gets one context wave and one chain wave — a workgroup's waves are dealt to the SIMDs
-// cyclically); the context wave's ~250 instructions per step fit into the issue slots the latency-bound
-// chain wave leaves empty.  All pairs of a workgroup run the same number of steps (the longest
-// substream's) so that the barrier counts match; surplus steps are no-ops.
+// ---- output stage of the two-wave encoder (runs on the context wave) ---------------------------------
+// The chain wave posts (low, pend) after bins 3, 7, 11, 15 of a step.  A post with pend >= 16 carries
+// pend / 16 whole 16-bit units (at most two) and possibly a carry above them; the units of one step are at
+// most eight per row.  quad_flush16 is the exact, serial rule for one unit.  Almost always every row is in
+// the plain state "one unit buffered, no 0xFFFF run, no new unit equals 0xFFFF, room in the buffer", and
+// then the rule degenerates to "store the previous unit plus the carry that arrived with this one": that
+// is done for all units of the four rows at once, lane k of a row taking unit k, through a small LDS list.
+// Anything else (first unit of a substream, 0xFFFF runs, a full buffer) takes the serial path.
+constexpr uint32_t kUnitSlots = 12;  // 8 units + spare + a dump slot for lanes that have nothing to list
+constexpr uint32_t kUnitDump = 11;
+
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v) {  // lane j gets lane j - N of its row, 0 below
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
+}
+
+// Part 1: lanes 0..3 of a row list the units of posts 0..3 in stream order; returns the row's unit count.
+__device__ __forceinline__ uint32_t quad_list_units(const uint32_t *plo, const uint32_t *phi, const uint32_t *ppend,
+                                                    uint32_t row, uint32_t j, uint32_t *list) {
+  const uint32_t c = (j & 3u) * kQuadSubs + row;  // lanes >= 4 read along, and count nothing
+  const uint64_t low = ((uint64_t)phi[c] << 32) | plo[c];
+  const uint32_t pend = ppend[c];
+  const uint32_t nun = j < 4u ? pend >> 4 : 0u;   // 0, 1 or 2 units
+  const uint64_t v = low >> (9u + (pend & 15u));  // carry, then the units
+  uint32_t incl = nun + row_shr<1>(nun);
+  incl += row_shr<2>(incl);
+  const uint32_t idx = incl - nun;
+  const uint32_t lead1 = (uint32_t)(v >> (16u * (nun - 1u) & 31u));  // carry + first unit (nun >= 1)
+  const uint32_t lead2 = (uint32_t)v & 0xffffu;                      // second unit (nun == 2)
+  list[nun >= 1u ? idx : kUnitDump] = lead1;
+  list[nun == 2u ? idx + 1u : kUnitDump] = lead2;
+  return row_bcast<3>(incl);
+}
+
+// Part 2: emit.  Returns false if some row is not in the plain state (nothing has been changed then).
+__device__ __forceinline__ bool quad_emit_units(QuadEnc &e, uint32_t m, uint32_t j, bool live, const uint32_t *list) {
+  const uint32_t before = list[(j != 0u && j < m) ? j - 1u : kUnitDump];
+  const uint32_t mine = list[j < m ? j : kUnitDump];
+  const uint32_t last = list[m != 0u ? m - 1u : kUnitDump];
+  const bool odd = m != 0u && (e.nbuf != 1 || e.pos + 2u * m > e.cap || (j < m && (mine & 0x1ffffu) == 0xffffu));
+  if (__ballot(odd) != 0) return false;
+  const uint32_t prev = j == 0u ? e.buf : (before & 0xffffu);
+  const uint32_t unit = prev + (mine >> 16);  // buf + carry (writeOut, arith_codec.cpp:524-546, in base 2^16)
+  if (live && j < m) {
+    *reinterpret_cast<uint16_t *>(e.dst + e.pos + 2u * j) = (uint16_t)(((unit & 0xffu) << 8) | ((unit >> 8) & 0xffu));
+  }
+  e.buf = m != 0u ? (last & 0xffffu) : e.buf;
+  e.pos += 2u * m;
+  return true;
+}
+
+// the serial path: the posts of one step, unit by unit
+__device__ __forceinline__ void quad_flush_posts(QuadEnc &e, const uint32_t *plo, const uint32_t *phi, const uint32_t *ppend,
+                                                 uint32_t row, bool writer) {
+  for (uint32_t c = 0; c < 4; c++) {
+    e.low = ((uint64_t)phi[c * kQuadSubs + row] << 32) | plo[c * kQuadSubs + row];
+    e.pend = (int32_t)ppend[c * kQuadSubs + row];
+    while (e.pend >= 16) quad_flush16(e, writer);
+  }
+}
+
+// encode, TWO waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead, owns the LDS
+// context stores and writes the output; a chain wave runs the range / low recurrence and nothing else.
+// The two never wait on each other's memory: the hand-offs are one packed word per bin through a
+// double-buffered LDS mailbox (context -> chain), the posted (low, pend) of every 4th bin (chain -> context,
+// see QuadPost) and one workgroup barrier per 16-bin step.  A wave issues at most one instruction per ~4.4
+// cycles while a SIMD executes one per ~2.2 (tools/ubench_ilp.hip), so two waves per SIMD run side by side
+// at full speed and the kernel's time is the longer of the two instruction streams.
+// All pairs of a workgroup run the same number of steps (the longest substream's) so that the barrier
+// counts match; surplus steps are no-ops.
 template <int U>
 __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                             const uint16_t *__restrict__ records,
@@ -320,7 +393,9 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
                                                             cabac_substream_result *__restrict__ results) {
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t mail_all[U][2][64];
-  __shared__ uint32_t bad_rows[U];
+  __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];
+  __shared__ uint32_t fin_lo[U][kQuadSubs], fin_hi[U][kQuadSubs], fin_pend[U][kQuadSubs];
+  __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave
@@ -341,6 +416,17 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     const uint16_t *rec = records + d.rec_offset;
     uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
     quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+    QuadEnc e;  // output state; low / pend are loaded from the chain wave's posts
+    e.low = 0;
+    e.range = 0;
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    uint32_t *list = unit_list[unit][row];
     uint32_t bad = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t cur_rec = j < n ? rec[j] : 0;
@@ -349,56 +435,65 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     __syncthreads();
     uint32_t slot = 1;
     for (uint32_t base = 0; base < max_n; base += 16) {
-      // while the chain wave codes step `base`, prepare step base + 16
+      // while the chain wave codes step `base`: write out what it posted during step base - 16 (the listing
+      // before and the emission after phase (a), so that the LDS round trips hide behind it) ...
+      uint32_t m = 0;
+      if (base != 0) m = quad_list_units(post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, list);
+      // ... and prepare step base + 16
       const uint32_t r = next_rec;
       {
         const uint32_t nxt = base + 32u + j;
         next_rec = nxt < n ? rec[nxt] : 0;
       }
-      mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
+      const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
+      if (base != 0 && !quad_emit_units(e, m, j, live, list))
+        quad_flush_posts(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, writer);
+      mail[slot][lane] = info;
       slot ^= 1u;
       __syncthreads();
     }
+    __syncthreads();  // the chain wave has posted its last step and what it still holds
+    if (max_n != 0) quad_flush_posts(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, writer);
+    e.low = ((uint64_t)fin_hi[unit][row] << 32) | fin_lo[unit][row];
+    e.pend = (int32_t)fin_pend[unit][row];
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
     const uint64_t bad_mask = __ballot(bad != 0);
-    if (lane == 0) {
-      uint32_t rows = 0;
-      for (uint32_t k = 0; k < 4; k++) rows |= ((bad_mask >> (16u * k)) & 0xffffull) ? (1u << k) : 0u;
-      bad_rows[unit] = rows;
+    const bool row_bad = ((bad_mask >> (row * 16u)) & 0xffffull) != 0;
+    if (writer) {
+      cabac_substream_result res;
+      res.n_bits = n_bits;
+      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (row_bad ? CABAC_RES_BAD_RECORD : 0u);
+      results[sub] = res;
     }
-    __syncthreads();
   } else {
     // ---- chain wave --------------------------------------------------------------------------
-    // the chain is the critical path: let it win issue arbitration against the context wave that shares its
-    // SIMD (the context wave then only fills the slots the chain's dependencies leave empty)
+    // its instruction stream is the longer one: let it win issue arbitration against the context wave
     __builtin_amdgcn_s_setprio(3);
     QuadEnc e;
     e.low = 0;
     e.range = 510;  // start(), arith_codec.cpp:329-337
     e.pend = 0;
-    e.buf = 0;
-    e.nbuf = 0;
-    e.pos = 0;
-    e.dst = bytes + d.byte_offset;
-    e.cap = live ? d.byte_capacity : 0u;
-    const bool writer = live && j == 0;
+    const bool poster = j == 0;
     __syncthreads();
     uint32_t slot = 0;
     for (uint32_t base = 0; base < max_n; base += 16) {
       const uint32_t info = mail[slot][lane];
+      QuadPost post;
+      post.lo = &post_lo[unit][slot][row];
+      post.hi = &post_hi[unit][slot][row];
+      post.pend = &post_pend[unit][slot][row];
       slot ^= 1u;
       const QuadEncInfo f = quad_unpack(info);
-      if (__ballot(info >> 12) == 0) quad_enc_steps<false>(f, e, writer);
-      else quad_enc_steps<true>(f, e, writer);
+      if (__ballot(info >> 12) == 0) quad_enc_steps<false, true>(f, e, poster, post);
+      else quad_enc_steps<true, true>(f, e, poster, post);
       __syncthreads();
     }
-    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
-    __syncthreads();
-    if (writer) {
-      cabac_substream_result res;
-      res.n_bits = n_bits;
-      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
-      results[sub] = res;
+    if (poster) {
+      fin_lo[unit][row] = (uint32_t)e.low;
+      fin_hi[unit][row] = (uint32_t)(e.low >> 32);
+      fin_pend[unit][row] = (uint32_t)e.pend;
     }
+    __syncthreads();
   }
 }
 

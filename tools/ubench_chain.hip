@@ -19,7 +19,7 @@ __global__ void chain_bench(unsigned long long *cyc, unsigned *sink, int iters, 
     if (!is_ep) info = ((x >> 8) & 31u) | (8u << 5) | (((x >> 20) & 7u) == 0 ? (1u << 9) : 0u);
     else info = (1u << 10) | (((x >> 13) & 1u) << 11);
     const QuadEncInfo f = quad_unpack(info);
-    quad_enc_steps<false>(f, e, false);
+    quad_enc_steps<false, false>(f, e, false, QuadPost());
     if (e.pos > 60000) e.pos = 0;
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
