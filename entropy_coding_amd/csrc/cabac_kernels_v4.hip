@@ -39,16 +39,20 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, true);  // bound_ctrl: no old-value init
 }
 
+// Lanes (of `lanes`) that hold the same BITS-bit key as this lane.  One ballot per key bit; each lane keeps
+// the lanes that agree with it on that bit: m &= ~(ballot ^ mybit), with the lane's bit spread to a 0 / ~0
+// word so that the whole round is four vector instructions (bfe, cmp, 2 x bitop3) and no scalar one.
 template <int BITS>
-__device__ __forceinline__ uint64_t match_any_bits(uint32_t key) {
-  uint64_t m = ~0ull;
+__device__ __forceinline__ uint64_t match_any_bits(uint32_t key, uint64_t lanes) {
+  uint32_t mlo = (uint32_t)lanes, mhi = (uint32_t)(lanes >> 32);
 #pragma unroll
   for (int b = 0; b < BITS; b++) {
-    const bool bit = (key >> b) & 1u;
-    const uint64_t bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
+    const uint32_t mine = (uint32_t)((int32_t)(key << (31 - b)) >> 31);
+    const uint64_t bal = __ballot(mine != 0);
+    mlo &= ~((uint32_t)bal ^ mine);
+    mhi &= ~((uint32_t)(bal >> 32) ^ mine);
   }
-  return m;
+  return ((uint64_t)mhi << 32) | mlo;
 }
 
 // 0 / ~0 from one bit of x
@@ -90,12 +94,9 @@ __device__ __forceinline__ void quad_put16(QuadEnc &e, uint32_t unit, bool write
   e.pos += 2;
 }
 
-// peel 16 bits off the top of low; delayed carry as writeOut (arith_codec.cpp:524-546) in base 2^16
-__device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
-  const uint32_t sh = (uint32_t)(9 + e.pend - 16);
-  const uint32_t lead = (uint32_t)(e.low >> sh);  // carry + 16 bits
-  e.low &= (1ull << sh) - 1ull;
-  e.pend -= 16;
+// one 16-bit unit with the carry that arrived on top of it (lead = carry << 16 | unit): delayed carry as
+// writeOut (arith_codec.cpp:524-546), in base 2^16
+__device__ __forceinline__ void quad_flush_lead(QuadEnc &e, uint32_t lead, bool writer) {
   const bool is_ff = lead == 0xffffu;
   const bool emit = !is_ff && e.nbuf > 0;
   const uint32_t carry = lead >> 16;
@@ -107,6 +108,15 @@ __device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
     quad_put16(e, first, writer);
     for (int32_t k = 0; k < fill_n; k++) quad_put16(e, 0xffffu + carry, writer);
   }
+}
+
+// peel 16 bits (and the carry above them) off the top of low
+__device__ __forceinline__ void quad_flush16(QuadEnc &e, bool writer) {
+  const uint32_t sh = (uint32_t)(9 + e.pend - 16);
+  const uint32_t lead = (uint32_t)(e.low >> sh);  // carry + 16 bits
+  e.low &= (1ull << sh) - 1ull;
+  e.pend -= 16;
+  quad_flush_lead(e, lead, writer);
 }
 
 // Where the chain wave of the two-wave encoder (v5) leaves its output: every 4th bin it posts (low, pend) to LDS
@@ -188,23 +198,36 @@ __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32
   const bool is_trm = active && id == CABAC_REC_TRM;
   const bool is_align = active && id == CABAC_REC_ALIGN;
   if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
-  const uint64_t same = match_any_bits<11>(id | (row << 9));
-  const uint64_t before = same & lt_mask;
-  const uint32_t prev = 63u - (uint32_t)__builtin_clzll(before | 1ull);
-  const bool is_last = (same & ~lt_mask & ~(1ull << lane)) == 0;
+  const uint32_t j = lane & 15u;
+  const uint32_t same = (uint32_t)(match_any_bits<9>(id, 0xffffull << (16u * row)) >> (16u * row)) & 0xffffu;
+  const uint32_t binmask = (uint32_t)(__ballot(bin != 0) >> (16u * row)) & 0xffffu;  // the bins of this row
+  const uint32_t before = same & ((1u << j) - 1u);      // earlier bins of the same context in this step
+  const bool is_last = (same >> j) == 1u;                // no later one
   uint32_t st = is_ctx ? rctx[id] : 0u;
-  bool pending = is_ctx && before != 0;
-  for (;;) {
-    const uint64_t pend = __ballot(pending);
-    if (pend == 0) break;
-    const uint32_t post = ctx2_update(st, bin);
-    const uint32_t pulled = __shfl(post, (int)prev);
-    if (pending && !((pend >> prev) & 1ull)) {  // the previous bin of this context is settled
-      st = pulled;
-      pending = false;
-    }
+  // The state this bin sees is the stored one updated by those earlier bins, oldest first.  Their values are
+  // known (encoder), so every lane walks its own `before` set — no hand-over between lanes, hence no LDS
+  // round trip per repetition of a context.  update(), contexts.cpp:903-913, on both 15-bit estimators at
+  // once with packed 16-bit math as in the decoder (the rates of a context never change).
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const uint32_t r0 = (st & 3u) + 2u, r1 = ((st >> 2) & 7u) + 5u;
+  const u16x2 rate2 = __builtin_bit_cast(u16x2, r0 | (r1 << 16));
+  const u16x2 add2 = __builtin_bit_cast(u16x2, ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16));
+  const u16x2 mask2 = __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
+  auto updated = [&](uint32_t s, uint32_t b) {
+    const u16x2 s2 = __builtin_bit_cast(u16x2, s);
+    const u16x2 b2 = __builtin_bit_cast(u16x2, b | (b << 16));
+    return __builtin_bit_cast(uint32_t, (u16x2)(add2 * b2 + (s2 - ((s2 >> rate2) & mask2))));
+  };
+  uint32_t todo = is_ctx ? before : 0u;
+  for (int round = 0;; round++) {  // two repetitions unconditionally (mask arithmetic, no branch), more if needed
+    if (round >= 2 && __ballot(todo != 0) == 0) break;
+    const uint32_t valid = (uint32_t)((int32_t)(0u - todo) >> 31);
+    const uint32_t which = (uint32_t)__builtin_ctz(todo | 0x10000u);
+    const uint32_t b = (binmask >> which) & 1u;
+    st = sel(valid, updated(st, b), st);
+    todo &= todo - 1u;
   }
-  if (is_ctx && is_last) rctx[id] = ctx2_update(st, bin);
+  if (is_ctx && is_last) rctx[id] = updated(st, bin);
   const uint32_t q8 = ctx2_q8(st);
   const uint32_t mps = q8 >> 7;
   uint32_t info = 0;  // inactive lanes: a no-op step (t = 0, no shift)
@@ -332,49 +355,71 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {  // lane j gets lane j
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
 }
 
-// Part 1: lanes 0..3 of a row list the units of posts 0..3 in stream order; returns the row's unit count.
-__device__ __forceinline__ uint32_t quad_list_units(const uint32_t *plo, const uint32_t *phi, const uint32_t *ppend,
-                                                    uint32_t row, uint32_t j, uint32_t *list) {
+// Everything below is written with 0 / ~0 masks in VGPRs: boolean expressions become lane masks in SGPRs,
+// and every scalar instruction that consumes a vector result stalls the wave for ~55 cycles.
+__device__ __forceinline__ uint32_t neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }  // ~0 if bit 31 set
+
+struct QuadUnits {
+  uint32_t m;            // units of this step in the row (0..8)
+  uint64_t odd_rows;     // lanes of rows that are not in the plain state (before looking at the units themselves);
+                         // kept as the raw mask: a scalar compare right behind the v_cmp would wait for it
+  uint64_t store_lanes;  // lanes that will store a unit
+};
+
+// Part 1: lanes 0..3 of a row list the units of posts 0..3 in stream order.
+__device__ __forceinline__ QuadUnits quad_list_units(const QuadEnc &e, const uint32_t *plo, const uint32_t *phi,
+                                                     const uint32_t *ppend, uint32_t row, uint32_t j, bool live,
+                                                     uint32_t *list) {
   const uint32_t c = (j & 3u) * kQuadSubs + row;  // lanes >= 4 read along, and count nothing
   const uint64_t low = ((uint64_t)phi[c] << 32) | plo[c];
   const uint32_t pend = ppend[c];
-  const uint32_t nun = j < 4u ? pend >> 4 : 0u;   // 0, 1 or 2 units
-  const uint64_t v = low >> (9u + (pend & 15u));  // carry, then the units
+  const uint32_t nun = (pend >> 4) & neg_mask(j - 4u);  // 0, 1 or 2 units
+  const uint64_t v = low >> (9u + (pend & 15u));         // carry, then the units
   uint32_t incl = nun + row_shr<1>(nun);
   incl += row_shr<2>(incl);
   const uint32_t idx = incl - nun;
-  const uint32_t lead1 = (uint32_t)(v >> (16u * (nun - 1u) & 31u));  // carry + first unit (nun >= 1)
-  const uint32_t lead2 = (uint32_t)v & 0xffffu;                      // second unit (nun == 2)
-  list[nun >= 1u ? idx : kUnitDump] = lead1;
-  list[nun == 2u ? idx + 1u : kUnitDump] = lead2;
-  return row_bcast<3>(incl);
+  const uint32_t first = (uint32_t)(v >> (((nun - 1u) & 1u) << 4));  // carry + first unit (nun >= 1)
+  const uint32_t second = (uint32_t)v & 0xffffu;                      // second unit (nun == 2)
+  const uint32_t has1 = neg_mask(0u - nun);                           // nun >= 1
+  const uint32_t has2 = neg_mask(1u - nun);                           // nun == 2
+  list[sel(has1, idx, kUnitDump)] = first;
+  list[sel(has2, idx + 1u, kUnitDump)] = second;
+  QuadUnits u;
+  u.m = row_bcast<3>(incl);
+  const uint32_t room = e.cap - e.pos - 2u * u.m;                     // negative: the buffer would overflow
+  const uint32_t rowodd = neg_mask(0u - u.m) & (neg_mask(0u - ((uint32_t)e.nbuf ^ 1u)) | neg_mask(room));
+  u.odd_rows = __ballot(rowodd != 0);
+  u.store_lanes = __ballot(live && j < u.m);
+  return u;
 }
 
-// Part 2: emit.  Returns false if some row is not in the plain state (nothing has been changed then).
-__device__ __forceinline__ bool quad_emit_units(QuadEnc &e, uint32_t m, uint32_t j, bool live, const uint32_t *list) {
-  const uint32_t before = list[(j != 0u && j < m) ? j - 1u : kUnitDump];
-  const uint32_t mine = list[j < m ? j : kUnitDump];
-  const uint32_t last = list[m != 0u ? m - 1u : kUnitDump];
-  const bool odd = m != 0u && (e.nbuf != 1 || e.pos + 2u * m > e.cap || (j < m && (mine & 0x1ffffu) == 0xffffu));
-  if (__ballot(odd) != 0) return false;
-  const uint32_t prev = j == 0u ? e.buf : (before & 0xffffu);
+// the serial path: the listed units of one step, one by one
+__device__ __forceinline__ void quad_flush_list(QuadEnc &e, uint32_t m, const uint32_t *list, bool writer) {
+  for (uint32_t k = 0; k < 8u && __ballot(k < m) != 0; k++) {
+    if (k < m) quad_flush_lead(e, list[k], writer);
+  }
+}
+
+// Part 2: emit the listed units (one step later, so that neither the list nor the masks are waited for).
+__device__ __forceinline__ void quad_emit_units(QuadEnc &e, const QuadUnits &u, uint32_t j, const uint32_t *list,
+                                                bool writer) {
+  if (u.odd_rows != 0) return quad_flush_list(e, u.m, list, writer);
+  const uint32_t act = neg_mask(j - u.m);  // lane j holds unit j
+  const uint32_t jnz = neg_mask(0u - j);
+  const uint32_t before = list[sel(act & jnz, j - 1u, kUnitDump)];
+  const uint32_t mine = list[sel(act, j, kUnitDump)];
+  const uint32_t last = list[sel(neg_mask(0u - u.m), u.m - 1u, kUnitDump)];
+  const uint32_t x = (mine & 0x1ffffu) ^ 0xffffu;  // 0: no carry, unit 0xFFFF — starts or extends a run
+  if (__ballot((act & neg_mask(x - 1u)) != 0) != 0) return quad_flush_list(e, u.m, list, writer);
+  const uint32_t prev = sel(jnz, before & 0xffffu, e.buf);
   const uint32_t unit = prev + (mine >> 16);  // buf + carry (writeOut, arith_codec.cpp:524-546, in base 2^16)
-  if (live && j < m) {
-    *reinterpret_cast<uint16_t *>(e.dst + e.pos + 2u * j) = (uint16_t)(((unit & 0xffu) << 8) | ((unit >> 8) & 0xffu));
-  }
-  e.buf = m != 0u ? (last & 0xffffu) : e.buf;
-  e.pos += 2u * m;
-  return true;
-}
-
-// the serial path: the posts of one step, unit by unit
-__device__ __forceinline__ void quad_flush_posts(QuadEnc &e, const uint32_t *plo, const uint32_t *phi, const uint32_t *ppend,
-                                                 uint32_t row, bool writer) {
-  for (uint32_t c = 0; c < 4; c++) {
-    e.low = ((uint64_t)phi[c * kQuadSubs + row] << 32) | plo[c * kQuadSubs + row];
-    e.pend = (int32_t)ppend[c * kQuadSubs + row];
-    while (e.pend >= 16) quad_flush16(e, writer);
-  }
+  const uint32_t be = ((unit & 0xffu) << 8) | ((unit >> 8) & 0xffu);
+  uint8_t *addr = e.dst + e.pos + 2u * j;
+  uint64_t saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_short %2, %3, off\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "s"(u.store_lanes), "v"(addr), "v"(be) : "memory");
+  e.buf = sel(neg_mask(0u - u.m), last & 0xffffu, e.buf);
+  e.pos += 2u * u.m;
 }
 
 // encode, TWO waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead, owns the LDS
@@ -386,6 +431,16 @@ __device__ __forceinline__ void quad_flush_posts(QuadEnc &e, const uint32_t *plo
 // at full speed and the kernel's time is the longer of the two instruction streams.
 // All pairs of a workgroup run the same number of steps (the longest substream's) so that the barrier
 // counts match; surplus steps are no-ops.
+#ifdef CABAC_V5_PROFILE  // tools/ubench_v5.hip: where the two waves of workgroup 0 spend their cycles
+__device__ unsigned long long g_v5_prof[16];
+#define V5_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define V5_ADD(slot, t0, t1) \
+  if (blockIdx.x == 0 && lane == 0) g_v5_prof[slot] += (t1) - (t0)
+#else
+#define V5_TICK(var)
+#define V5_ADD(slot, t0, t1)
+#endif
+
 template <int U>
 __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                             const uint16_t *__restrict__ records,
@@ -434,26 +489,46 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, lt_mask, bad);  // step 0
     __syncthreads();
     uint32_t slot = 1;
+    QuadUnits units;
+    units.m = 0;
+    units.odd_rows = 0;
+    units.store_lanes = 0;
+    bool listed = false;
     for (uint32_t base = 0; base < max_n; base += 16) {
-      // while the chain wave codes step `base`: write out what it posted during step base - 16 (the listing
-      // before and the emission after phase (a), so that the LDS round trips hide behind it) ...
-      uint32_t m = 0;
-      if (base != 0) m = quad_list_units(post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, list);
+      // While the chain wave codes step `base`: write out the units listed one iteration ago (posted during step
+      // base - 32) and list what was posted during step base - 16.  Loads and stores share one counter (vmcnt), so
+      // a wait for the record load also waits for every store issued before it: the load is waited for first,
+      // then the stores are issued, then the next load — by the next iteration both are long done.
+      uint32_t r = next_rec;
+      asm volatile("" : "+v"(r));  // wait for the record load HERE, while no store is in flight (see above)
+      V5_TICK(t0);
+      if (listed) quad_emit_units(e, units, j, list, writer);
+      V5_TICK(t1);
+      listed = base != 0;
+      if (listed) units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
+      V5_TICK(t2);
       // ... and prepare step base + 16
-      const uint32_t r = next_rec;
       {
         const uint32_t nxt = base + 32u + j;
         next_rec = nxt < n ? rec[nxt] : 0;
       }
       const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
-      if (base != 0 && !quad_emit_units(e, m, j, live, list))
-        quad_flush_posts(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, writer);
       mail[slot][lane] = info;
       slot ^= 1u;
+      V5_TICK(t3);
       __syncthreads();
+      V5_TICK(t4);
+      V5_ADD(0, t0, t1);  // emit
+      V5_ADD(1, t1, t2);  // list
+      V5_ADD(2, t2, t3);  // phase (a)
+      V5_ADD(3, t3, t4);  // waiting at the barrier
     }
     __syncthreads();  // the chain wave has posted its last step and what it still holds
-    if (max_n != 0) quad_flush_posts(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, writer);
+    if (listed) quad_emit_units(e, units, j, list, writer);
+    if (max_n != 0) {
+      units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
+      quad_emit_units(e, units, j, list, writer);
+    }
     e.low = ((uint64_t)fin_hi[unit][row] << 32) | fin_lo[unit][row];
     e.pend = (int32_t)fin_pend[unit][row];
     const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
@@ -484,9 +559,14 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
       post.pend = &post_pend[unit][slot][row];
       slot ^= 1u;
       const QuadEncInfo f = quad_unpack(info);
+      V5_TICK(t0);
       if (__ballot(info >> 12) == 0) quad_enc_steps<false, true>(f, e, poster, post);
       else quad_enc_steps<true, true>(f, e, poster, post);
+      V5_TICK(t1);
       __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(4, t0, t1);  // chain
+      V5_ADD(5, t1, t2);  // waiting at the barrier
     }
     if (poster) {
       fin_lo[unit][row] = (uint32_t)e.low;

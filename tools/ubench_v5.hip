@@ -1,0 +1,38 @@
+// Where the two waves of the v5 encoder spend their cycles (workgroup 0, s_memtime around the parts of the loop).
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCABAC_V5_PROFILE -Iinclude -Ientropy_coding_amd/csrc tools/ubench_v5.hip entropy_coding_amd/csrc/cabac_synth.cpp -o tools/ubench_v5
+#include "../entropy_coding_amd/csrc/cabac_kernels_v4.hip"
+#include <cstdio>
+#include <vector>
+using namespace cabac;
+
+int main() {
+  const uint32_t n_sub = 4096, n_bins = 16384;
+  std::vector<uint16_t> rec((size_t)n_sub * n_bins);
+  for (uint32_t s = 0; s < n_sub; s++) cabac_synth_records(0xC4, s, n_bins, 750, rec.data() + (size_t)s * n_bins);
+  std::vector<cabac_substream_desc> desc(n_sub);
+  const uint32_t cap = 16384 * 2 / 8 + 4096;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    desc[s].rec_offset = (uint64_t)s * n_bins; desc[s].byte_offset = (uint64_t)s * cap; desc[s].n_records = n_bins;
+    desc[s].byte_capacity = cap; desc[s].qp = 32; desc[s].init_id = 2 | CABAC_SUB_FINISH | CABAC_SUB_ALIGN_RBSP;
+  }
+  cabac_substream_desc *d_desc; uint16_t *d_rec; uint8_t *d_bytes; cabac_substream_result *d_res;
+  (void)hipMalloc(&d_desc, desc.size() * sizeof(desc[0])); (void)hipMalloc(&d_rec, rec.size() * 2);
+  (void)hipMalloc(&d_bytes, (size_t)n_sub * cap); (void)hipMalloc(&d_res, n_sub * sizeof(cabac_substream_result));
+  (void)hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(desc[0]), hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_rec, rec.data(), rec.size() * 2, hipMemcpyHostToDevice);
+  for (int rep = 0; rep < 3; rep++) {
+    unsigned long long zero[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), zero, sizeof(zero));
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(n_sub / 4), dim3(128), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+    (void)hipEventRecord(b); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    unsigned long long p[16];
+    (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_v5_prof), sizeof(p));
+    const double g = n_bins / 16.0;
+    printf("kernel %.3f ms; cycles per 16-bin step, workgroup 0: context wave emit %.0f list %.0f phase(a) %.0f barrier %.0f | chain wave chain %.0f barrier %.0f\n",
+           ms, p[0] / g, p[1] / g, p[2] / g, p[3] / g, p[4] / g, p[5] / g);
+  }
+  return 0;
+}
