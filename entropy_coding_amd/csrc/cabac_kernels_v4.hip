@@ -730,14 +730,24 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   w.range = 510;
   uint32_t bad = 0;
 
-  uint32_t next_rec = j < n ? rec[j] : 0;
-  for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
+  // Loop bound and loads without lane conditions: an exec region or a branch on a vector compare makes the
+  // scalar unit wait for the vector result (~55 cycles each, per step).  The longest row's length is made
+  // scalar once; loads past the end of a row read a valid address and are ignored (`active`).
+  uint32_t n_wave = n;
+  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 16));
+  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 32));
+  const uint32_t max_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_wave);
+  const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
+  const uint32_t last_rec = n != 0 ? n - 1u : 0u;
+  uint32_t next_rec = rec_safe[min(j, last_rec)];
+  for (uint32_t base = 0; base < max_n; base += 16) {
     const uint32_t r = next_rec;  // loaded one step ago
     const bool active = base + j < n;
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const bool is_ctx = id < (uint32_t)kNumCtx;
     if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
-    uint32_t st_v = is_ctx ? rctx[id] : 0u;
+    const uint32_t stored = rctx[min(id, (uint32_t)kNumCtx)];  // slot kNumCtx is the row's pad word
+    uint32_t st_v = is_ctx ? stored : 0u;
     const uint32_t r0 = (st_v & 3u) + 2u, r1 = ((st_v >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
     const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
@@ -752,10 +762,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     f.alm = is_align ? ~0u : 0u;
     f.key = is_ctx ? id : (0x200u + j);
     const bool any_special = __ballot(is_align || is_trm) != 0;
-    {  // prefetch the next step's records (see encode)
-      const uint32_t nxt = base + 16u + j;
-      next_rec = nxt < n ? rec[nxt] : 0;
-    }
+    next_rec = rec_safe[min(base + 16u + j, last_rec)];  // prefetch the next step's records
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
     if (!any_special) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
     else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
