@@ -203,7 +203,8 @@ __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32
   const uint32_t binmask = (uint32_t)(__ballot(bin != 0) >> (16u * row)) & 0xffffu;  // the bins of this row
   const uint32_t before = same & ((1u << j) - 1u);      // earlier bins of the same context in this step
   const bool is_last = (same >> j) == 1u;                // no later one
-  uint32_t st = is_ctx ? rctx[id] : 0u;
+  const uint32_t stored = rctx[min(id, (uint32_t)kNumCtx)];  // unconditional load (slot kNumCtx: the row's pad word)
+  uint32_t st = is_ctx ? stored : 0u;
   // The state this bin sees is the stored one updated by those earlier bins, oldest first.  Their values are
   // known (encoder), so every lane walks its own `before` set — no hand-over between lanes, hence no LDS
   // round trip per repetition of a context.  update(), contexts.cpp:903-913, on both 15-bit estimators at
@@ -484,8 +485,12 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     uint32_t *list = unit_list[unit][row];
     uint32_t bad = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t cur_rec = j < n ? rec[j] : 0;
-    uint32_t next_rec = 16u + j < n ? rec[16u + j] : 0;
+    // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
+    // past the end of a row they read a valid address and phase (a) ignores the value
+    const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
+    const uint32_t last_rec = n != 0 ? n - 1u : 0u;
+    const uint32_t cur_rec = rec_safe[min(j, last_rec)];
+    uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
     mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, lt_mask, bad);  // step 0
     __syncthreads();
     uint32_t slot = 1;
@@ -508,10 +513,7 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
       if (listed) units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
       V5_TICK(t2);
       // ... and prepare step base + 16
-      {
-        const uint32_t nxt = base + 32u + j;
-        next_rec = nxt < n ? rec[nxt] : 0;
-      }
+      next_rec = rec_safe[min(base + 32u + j, last_rec)];
       const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
       mail[slot][lane] = info;
       slot ^= 1u;
@@ -632,7 +634,6 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   const uint32_t sum = (st & kMask0) + (st >> 16);
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
-  const uint32_t mps = sum >> 15;                                // 0 for a non-context record (st == 0)
   const uint32_t t = (__umul24(w.range >> 5, k) + row_bcast<I>(f.c2)) >> 1;
   const uint32_t rm = w.range - t;
   // scaledRange at the window's scale, 2^22 (2^21 for a bypass bin) * rm.  As a multiplication on purpose: hipcc
@@ -641,7 +642,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   const uint32_t sr = __umul24(rm, row_bcast<I>(f.srmul));
   const uint32_t e = w.hi - sr;                                  // value - scaledRange; both are below 2^31
   const uint32_t ngem = (uint32_t)((int32_t)e >> 31);            // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0
-  const uint32_t bin = (~ngem ^ mps) & 1u;
+  const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
   const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
   const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;          // getRenormBitsLPS; masked out when t == 0
   const uint32_t nsh = (gc & nl) | (((rm >> 8) ^ 1u) & ngem);    // MPS path: rm < 512, so 1 iff rm < 256
