@@ -6,6 +6,7 @@
  */
 #include "cabac_oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "cabac_ctx_tables.h"
@@ -834,4 +835,64 @@ int orc_count_emulations(const uint8_t *p, long n) {
     if (found != n) cnt++;
   }
   return cnt;
+}
+
+/* ---------------------------------------------------------------- bit estimator
+ * BitEstimatorBase / TBitEstimator, entropy_codec/arith_codec.cpp:603-711, with
+ * BinProbModel_Std::estFracBitsUpdate / estFracBits / estFracBitsTrm (common/contexts.cpp:922-937) and
+ * BinProbModelBase::estFracBitsEP (:880-884): the cost of a bin string in 1/32768 bit. */
+static const uint32_t k_frac_bits[512] = {CABAC_FRAC_BITS_TABLE_VALUES};
+enum { ORC_SCALE_BITS = 15 };
+
+static int estimate_record_run(ctx_store *c, const uint16_t *rec, long n, uint64_t *acc) {
+  uint64_t b = *acc;
+  for (long i = 0; i < n; i++) {
+    const unsigned id = rec[i] & CABAC_REC_ID_MASK, bin = rec[i] >> 15;
+    if (id < ORC_NUM_CTX) {
+      b += k_frac_bits[2 * ctx_state8(c, id) + bin]; /* estFracBitsUpdate, contexts.cpp:922-925 */
+      ctx_update(c, id, bin);
+    } else if (id == CABAC_REC_EP) {
+      b += 1u << ORC_SCALE_BITS; /* encodeBinEP, arith_codec.cpp:636-638 */
+    } else if (id == CABAC_REC_TRM) {
+      b += bin ? 0x3bfbbu : 0x0010cu; /* estFracBitsTrm, contexts.cpp:931-933 */
+    } else if (id == CABAC_REC_ALIGN) {
+      const uint64_t add = (1u << ORC_SCALE_BITS) - 1; /* align(), arith_codec.cpp:679-684 */
+      b = (b + add) & ~add;
+    } else {
+      return -2;
+    }
+  }
+  *acc = b;
+  return 0;
+}
+
+int orc_estimate_records(const uint16_t *rec, long n, int qp, int init_id, uint64_t *frac_bits) {
+  ctx_store c;
+  ctx_store_init(&c, qp, init_id);
+  *frac_bits = 0; /* reset(), arith_codec.cpp:623-626 */
+  return estimate_record_run(&c, rec, n, frac_bits);
+}
+
+/* ops: the binarisation helpers emit the same bins as for the encoder; encodeBinsEP / encodeRemAbsEP cost
+ * 1 bit per bypass bin (arith_codec.cpp:640-677), which is what their expansion into EP records gives. */
+int orc_estimate_ops(const uint32_t *ops, long n_ops, int qp, int init_id, uint64_t *frac_bits) {
+  const long n = orc_ops_to_records(ops, n_ops, 0, 0);
+  if (n < 0) return (int)n;
+  uint16_t *rec = (uint16_t *)malloc((size_t)(n ? n : 1) * sizeof(uint16_t));
+  if (!rec) return -1;
+  orc_ops_to_records(ops, n_ops, rec, n);
+  const int rc = orc_estimate_records(rec, n, qp, init_id, frac_bits);
+  free(rec);
+  return rc;
+}
+
+void orc_estimate_batch(const void *desc_, uint32_t first, uint32_t count, const uint16_t *records,
+                        uint64_t *frac_bits, uint32_t *flags) {
+  const cabac_substream_desc *desc = (const cabac_substream_desc *)desc_;
+  for (uint32_t s = first; s < first + count; s++) {
+    const cabac_substream_desc *d = &desc[s];
+    const int rc = orc_estimate_records(records + d->rec_offset, d->n_records, d->qp, (int)(d->init_id & 3),
+                                        &frac_bits[s]);
+    flags[s] = rc == -2 ? CABAC_RES_BAD_RECORD : 0;
+  }
 }

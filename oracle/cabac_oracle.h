@@ -70,6 +70,14 @@ void orc_decode_batch(const void *desc, uint32_t first, uint32_t count, const ui
 /* OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181 */
 int orc_count_emulations(const uint8_t *bytes, long n);
 
+/* Bit estimator (BitEstimator_Std, arith_codec.cpp:603-711): cost of a bin string in 1/32768 bit after
+ * reset(qp, initId).  Returns 0, or -2 on a bad record / op.  A bad record leaves *frac_bits at the cost of
+ * the records before it. */
+int orc_estimate_records(const uint16_t *rec, long n, int qp, int init_id, uint64_t *frac_bits);
+int orc_estimate_ops(const uint32_t *ops, long n_ops, int qp, int init_id, uint64_t *frac_bits);
+void orc_estimate_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
+                        uint64_t *frac_bits, uint32_t *flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,22 @@ def main():
         out["case%d_bytes_finish" % k] = b1
         out["case%d_nbins" % k] = nbins
         out["case%d_values" % k] = vals
+    # (d) bit estimator (BitEstimator_Std): op streams -> fractional bits; own generator so that the vectors
+    # above stay what they were
+    rng2 = np.random.default_rng(20261005)
+    est = []
+    for n, frac, align in [(0, 0.5, False), (1, 1.0, False), (40, 0.0, True), (300, 0.6, True), (300, 0.95, False),
+                           (2000, 0.7, True), (2000, 0.4, True), (5000, 0.8, True), (64, 0.5, True), (999, 0.75, False)]:
+        ops = H.random_ops(rng2, n, ctx_frac=frac, with_align=align)
+        qp, iid = int(rng2.integers(0, 64)), int(rng2.integers(0, 3))
+        rc, bits = ref.estimate_ops(ops, qp, iid)
+        assert rc == 0
+        est.append((ops, qp, iid, bits))
+    out["est_n_cases"] = np.array(len(est), np.int32)
+    for k, (ops, qp, iid, bits) in enumerate(est):
+        out["est%d_ops" % k] = ops
+        out["est%d_meta" % k] = np.array([qp, iid], np.int32)
+        out["est%d_bits" % k] = np.array(bits, np.uint64)
     np.savez_compressed(os.path.join(GOLD, "vectors.npz"), **out)
 
     # (e) synthetic workloads C1..C5: md5 of the reference's bytes per substream

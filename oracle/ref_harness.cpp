@@ -303,4 +303,66 @@ int ref_count_emulations(const uint8_t *bytes, long n) {
   }
 }
 
+// ---- BitEstimator_Std (arith_codec.cpp:603-711): fractional-bit cost of a bin string -----------------
+// contexts.hpp:143 keeps the table protected; "contexts.hpp" is first included through cabac_writer.hpp
+// above, inside the access macros, so it is reachable here.
+int ref_frac_bits_table(uint32_t *out) {  // 256 x {bits of bin 0, bits of bin 1}, SCALE_BITS = 15
+  for (int q = 0; q < 256; q++) {
+    out[2 * q] = ProbModelTables::m_binFracBits[q].intBits[0];
+    out[2 * q + 1] = ProbModelTables::m_binFracBits[q].intBits[1];
+  }
+  return 256;
+}
+
+int ref_estimate_ops(const uint32_t *ops, long n_ops, int qp, int initId, uint64_t *frac_bits) {
+  try {
+    BitEstimator_Std est;
+    CABACWriter w(est);
+    est.reset(qp, initId);
+    BinEncIf &e = est;
+    for (long i = 0; i < n_ops; i++) {
+      const uint32_t *o = ops + 4 * i;
+      switch (o[0]) {
+      case OP_ENC_BIN: e.encodeBin(o[1], o[2]); break;
+      case OP_ENC_EP: e.encodeBinEP(o[1]); break;
+      case OP_ENC_BINS_EP: e.encodeBinsEP(o[1], o[2]); break;
+      case OP_ENC_REM_ABS: e.encodeRemAbsEP(o[1], o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
+      case OP_ENC_TRM: e.encodeBinTrm(o[1]); break;
+      case OP_ALIGN: e.align(); break;
+      case OP_UNARY_MAX: w.unary_max_symbol(o[1], o[2] & 0xffff, o[2] >> 16, o[3]); break;
+      case OP_UNARY_EP: w.unary_max_eqprob(o[1], o[2]); break;
+      case OP_EXP_GOLOMB: w.exp_golomb_eqprob(o[1], o[2]); break;
+      case OP_TRUNC_BIN: w.xWriteTruncBinCode(o[1], o[2]); break;
+      default: strcpy(g_err, "bad op"); return -2;
+      }
+    }
+    *frac_bits = est.getEstFracBits();
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+int ref_estimate_records(const uint16_t *rec, long n, int qp, int initId, uint64_t *frac_bits) {
+  try {
+    BitEstimator_Std est;
+    est.reset(qp, initId);
+    BinEncIf &e = est;
+    for (long i = 0; i < n; i++) {
+      unsigned id = rec[i] & 0x1ff, bin = rec[i] >> 15;
+      if (id < Ctx::NumberOfContexts) e.encodeBin(bin, id);
+      else if (id == 0x1fe) e.encodeBinEP(bin);
+      else if (id == 0x1ff) e.encodeBinTrm(bin);
+      else if (id == 0x1fd) e.align();
+      else { strcpy(g_err, "bad record"); return -2; }
+    }
+    *frac_bits = est.getEstFracBits();
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
 } // extern "C"

@@ -65,7 +65,13 @@ class CodecLib:
         g("ctx_init").argtypes = [ctypes.c_int, ctypes.c_int, u16p, u16p, u8p]
         g("ctx_trace").argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int, ctypes.c_uint,
                                    u8p, u8p, u16p, u16p]
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        g("estimate_ops").restype = ctypes.c_int
+        g("estimate_ops").argtypes = [u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u64p]
+        g("estimate_records").restype = ctypes.c_int
+        g("estimate_records").argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u64p]
         if prefix == "orc_":
+            L.orc_estimate_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u16p, u64p, u32p]
             L.orc_ops_to_records.restype = ctypes.c_long
             L.orc_ops_to_records.argtypes = [u32p, ctypes.c_long, u16p, ctypes.c_long]
             L.orc_encode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u16p, u8p, u32p]
@@ -142,6 +148,27 @@ class CodecLib:
         rec = np.zeros(max(n, 1), np.uint16)
         self.lib.orc_ops_to_records(_ptr(ops, u32p), len(ops), _ptr(rec, u16p), n)
         return rec[:n]
+
+    # -- bit estimator (BitEstimator_Std) --------------------------------------
+    def estimate_ops(self, ops, qp, init_id):
+        """(rc, fractional bits in 1/32768 bit) of an op stream after reset(qp, init_id)."""
+        ops = np.ascontiguousarray(ops, np.uint32).reshape(-1, 4)
+        out = ctypes.c_uint64(0)
+        rc = getattr(self.lib, self.p + "estimate_ops")(_ptr(ops, u32p), len(ops), qp, init_id, ctypes.byref(out))
+        return rc, out.value
+
+    def estimate_records(self, rec, qp, init_id):
+        rec = np.ascontiguousarray(rec, np.uint16)
+        out = ctypes.c_uint64(0)
+        rc = getattr(self.lib, self.p + "estimate_records")(_ptr(rec, u16p), len(rec), qp, init_id, ctypes.byref(out))
+        return rc, out.value
+
+    def estimate_batch(self, desc, records):
+        bits = np.zeros(len(desc), np.uint64)
+        flags = np.zeros(len(desc), np.uint32)
+        self.lib.orc_estimate_batch(desc.ctypes.data, 0, len(desc), _ptr(records, u16p),
+                                    bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _ptr(flags, u32p))
+        return bits, flags
 
     def encode_batch(self, desc, records, bytes_total):
         out = np.zeros(max(bytes_total, 1), np.uint8)

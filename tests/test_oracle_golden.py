@@ -22,11 +22,15 @@ def test_init_tables_header_matches_golden_blob():
     blob = open(os.path.join(H.GOLDEN, "ctx_init_tables.bin"), "rb").read()
     assert len(blob) == 4 * 379 and hashlib.md5(blob).hexdigest() == "96d432c564d403e474dd39432f771182"
     hdr = open(os.path.join(H.ROOT, "include", "cabac_ctx_tables.h")).read()
-    body = hdr.split("#define CABAC_CTX_INIT_TABLE_VALUES")[1]
+    body = hdr.split("#define CABAC_CTX_INIT_TABLE_VALUES")[1].split("#define CABAC_FRAC_BITS_TABLE_VALUES")[0]
     import re
-    body = re.sub(r"/\*.*?\*/", "", body)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     vals = [int(x) for x in re.findall(r"\d+", body)]
     assert bytes(vals) == blob
+    # the bit-estimator cost table in the same header, against its own golden blob
+    fb = np.fromfile(os.path.join(H.GOLDEN, "frac_bits_table.bin"), "<u4")
+    body = re.sub(r"/\*.*?\*/", "", hdr.split("#define CABAC_FRAC_BITS_TABLE_VALUES")[1], flags=re.S)
+    assert [int(x, 16) for x in re.findall(r"0x[0-9a-f]+", body)] == fb.tolist()
 
 
 def test_ctx_init(gold):
