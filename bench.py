@@ -197,6 +197,18 @@ def main():
                 hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
         del host_bytes
 
+    # ---- bit estimator on the same resident records, outside the timed region ----
+    t_est = torch.zeros(max(n_sub, 1), dtype=torch.int64, device="cuda")
+    t_est_flags = torch.zeros(max(n_sub, 1), dtype=torch.int32, device="cuda")
+    hip.estimate_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_est.data_ptr(), t_est_flags.data_ptr())
+    torch.cuda.synchronize()
+    hip.profile_enable(4)
+    for _ in range(4):
+        hip.estimate_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_est.data_ptr(), t_est_flags.data_ptr())
+    est_ms = float(np.mean([ms for k, ms in hip.profile_read() if k == 4]))
+    est_ok = not bool(t_est_flags.any().item())
+    est_bits_per_bin = float(t_est.sum().item()) / 32768.0 / max(n_bins, 1)
+
     # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
     gather_ms = None
     if world > 1:
@@ -266,6 +278,13 @@ def main():
                                  "traffic": measured_traffic(cfg.name, k_enc if dominant == "decode" else k_dec)},
             },
         }
+        line["estimate"] = {  # not part of `value`: BitEstimator_Std over the same bin strings
+            "kernel": "estimate_kernel", "kernel_ms": round(est_ms, 4),
+            "mbins_s": round(n_bins / (est_ms * 1e-3) / 1e6, 2),
+            "algorithmic_bytes_per_launch": 2 * n_bins + 48 * n_sub,
+            "achieved_gbps": round((2 * n_bins + 48 * n_sub) / (est_ms * 1e-3) / 1e9, 3),
+            "estimated_bits_per_bin": round(est_bits_per_bin, 5),
+            "coded_bits_per_bin": round(8.0 * out_bytes / max(n_bins, 1), 5), "flags_clear": est_ok}
         if gather_ms is not None:
             line["sizes_allgather_ms"] = round(gather_ms, 3)
         if world == 1 and not args.no_cpu_baseline:

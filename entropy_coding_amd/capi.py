@@ -25,6 +25,7 @@ EXPORTS = [
     "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
+    "cabac_hip_estimate_device",
 ]
 
 _lib = None
@@ -68,6 +69,7 @@ def load_library():
     L.cabac_hip_assemble_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint64, vp]
     L.cabac_hip_split_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_count_emulations_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
+    L.cabac_hip_estimate_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.cabac_synth_records.restype = None
@@ -103,6 +105,7 @@ class CabacHip:
         if rc != 0:
             raise CabacHipError(rc, "cabac_hip_init(device=%d)" % device)
         self.h = h
+        self.device = device
         if stream is not None:
             self._check(self.L.cabac_hip_set_stream(self.h, vp(stream)))
 
@@ -174,6 +177,26 @@ class CabacHip:
     def decode_device(self, n_sub, d_desc, d_records, d_bytes, d_bins, d_results):
         self._check(self.L.cabac_hip_decode_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_bytes), vp(d_bins),
                                                    vp(d_results)))
+
+    def estimate_device(self, n_sub, d_desc, d_records, d_frac_bits, d_flags=0):
+        """BitEstimator_Std over a batch of bin strings: d_frac_bits[s] (uint64) = cost in 1/32768 bit."""
+        self._check(self.L.cabac_hip_estimate_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_frac_bits),
+                                                     vp(d_flags) if d_flags else None))
+
+    def estimate_batch(self, desc, records):
+        """Host-array convenience over estimate_device (torch tensors as staging): (frac_bits, flags)."""
+        import torch
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        records = np.ascontiguousarray(records, np.uint16)
+        dev = "cuda:%d" % self.device
+        t_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
+        t_rec = torch.from_numpy(records.view(np.int16).copy() if len(records) else np.zeros(1, np.int16)).to(dev)
+        t_bits = torch.zeros(max(len(desc), 1), dtype=torch.int64, device=dev)
+        t_flags = torch.zeros(max(len(desc), 1), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)  # the staging copies ran on torch's stream, the kernel runs on the codec's
+        self.estimate_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), t_bits.data_ptr(), t_flags.data_ptr())
+        self.synchronize()
+        return (t_bits.cpu().numpy().view(np.uint64)[: len(desc)], t_flags.cpu().numpy().view(np.uint32)[: len(desc)])
 
     def binarize_device(self, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records):
         self._check(self.L.cabac_hip_binarize_device(self.h, n_sub, vp(d_se_offset), vp(d_se), vp(d_rec_offset),

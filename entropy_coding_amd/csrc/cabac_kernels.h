@@ -24,6 +24,10 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results);
 
+// bit estimator (cabac_kernels_v4.hip)
+hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t *frac_bits, uint32_t *flags);
+
 // device binariser (cabac_binarize.hip)
 hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_offset, const uint32_t *se,
                            const uint64_t *rec_offset, uint32_t *n_records, uint16_t *records);

@@ -189,8 +189,14 @@ __device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e,
 // Phase (a) of one 16-bin step for the four rows: the context state each bin sees, resolved in parallel
 // (see v3), the LDS context store brought up to date, and the bin's chain fields packed into one word:
 //   bits 4..0 k | bits 8..5 2c | bit 9 LPS path | bit 10 bypass | bit 11 bypass bin 1 | bit 12 align
-__device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                 uint64_t lt_mask, uint32_t &bad) {
+struct QuadRecord {  // one bin record of a 16-bin step, with the context state it sees
+  uint32_t id, bin, st;
+  bool is_ctx, is_ep, is_trm, is_align;
+};
+
+__device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
+                                                   uint32_t &bad) {
+  QuadRecord q;
   const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
   const uint32_t bin = (r >> 15) & 1u;
   const bool is_ctx = id < (uint32_t)kNumCtx;
@@ -229,13 +235,28 @@ __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32
     todo &= todo - 1u;
   }
   if (is_ctx && is_last) rctx[id] = updated(st, bin);
-  const uint32_t q8 = ctx2_q8(st);
+  q.id = id;
+  q.bin = bin;
+  q.st = st;
+  q.is_ctx = is_ctx;
+  q.is_ep = is_ep;
+  q.is_trm = is_trm;
+  q.is_align = is_align;
+  return q;
+}
+
+__device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
+                                                 uint64_t lt_mask, uint32_t &bad) {
+  (void)lt_mask;
+  const QuadRecord q = quad_resolve(r, active, lane, row, rctx, bad);
+  const uint32_t bin = q.bin;
+  const uint32_t q8 = ctx2_q8(q.st);
   const uint32_t mps = q8 >> 7;
   uint32_t info = 0;  // inactive lanes: a no-op step (t = 0, no shift)
-  if (is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) << 9);
-  if (is_trm) info = (4u << 5) | (bin << 9);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
-  if (is_ep) info = (1u << 10) | (bin << 11);
-  if (is_align) info = 1u << 12;
+  if (q.is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) << 9);
+  if (q.is_trm) info = (4u << 5) | (bin << 9);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
+  if (q.is_ep) info = (1u << 10) | (bin << 11);
+  if (q.is_align) info = 1u << 12;
   return info;
 }
 
@@ -794,6 +815,87 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     res.flags = flags;
     results[sub] = res;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bit estimator: BitEstimator_Std, arith_codec.cpp:603-711
+//
+// The cost of a bin string in 1/32768 bit: a context bin costs m_binFracBits[state][bin] and updates its
+// context (estFracBitsUpdate, contexts.cpp:922-925), a bypass bin 1 bit, a terminate bin a constant, and
+// align() rounds the running total up to a whole bit.  There is no low / range recurrence: the only serial
+// part is the context state each bin sees, which quad_resolve gives for 16 bins of four substreams at once.
+// Every lane adds up its own bins; the sixteen partial sums of a row meet at the end — and at an align
+// record, which needs the running total in order (rare: that step is then summed serially).
+static __constant__ uint32_t c_frac_bits[512] = {CABAC_FRAC_BITS_TABLE_VALUES};
+
+__device__ __forceinline__ uint64_t row_sum64(uint64_t v) {  // sum over the 16 lanes of a row, in every lane
+  for (int d = 1; d < 16; d <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                          const uint16_t *__restrict__ records,
+                                                          uint64_t *__restrict__ frac_bits, uint32_t *__restrict__ flags) {
+  __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
+  __shared__ uint32_t frac[512];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+  const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
+  const bool live = sub < n_sub;
+  const cabac_substream_desc d = desc[live ? sub : 0];
+  const uint32_t n = live ? d.n_records : 0u;
+  const uint16_t *rec = records + d.rec_offset;
+  uint32_t *rctx = ctx_all + (wave * kQuadSubs + row) * kQuadCtxStride;
+  quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+  for (uint32_t k = threadIdx.x; k < 512u; k += 64u * W) frac[k] = c_frac_bits[k];
+  __syncthreads();
+
+  uint32_t n_wave = n;
+  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 16));
+  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 32));
+  const uint32_t max_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_wave);
+  const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
+  const uint32_t last_rec = n != 0 ? n - 1u : 0u;
+  uint32_t next_rec = rec_safe[min(j, last_rec)];
+  uint32_t bad = 0;
+  uint64_t acc = 0;  // this lane's share of the row's total
+  for (uint32_t base = 0; base < max_n; base += 16) {
+    const uint32_t r = next_rec;
+    next_rec = rec_safe[min(base + 16u + j, last_rec)];
+    const QuadRecord q = quad_resolve(r, base + j < n, lane, row, rctx, bad);
+    uint32_t cost = 0;
+    if (q.is_ctx) cost = frac[2u * ctx2_q8(q.st) + q.bin];
+    if (q.is_ep) cost = 1u << 15;                     // estFracBitsEP, contexts.cpp:880-882
+    if (q.is_trm) cost = q.bin ? 0x3bfbbu : 0x0010cu;  // estFracBitsTrm, contexts.cpp:931-933
+    if (__builtin_expect(__ballot(q.is_align) != 0, 0)) {
+      uint64_t total = row_sum64(acc);  // everything before this step
+      for (int k = 0; k < 16; k++) {
+        total += (uint32_t)__shfl((int)cost, (int)(row * 16u + k));
+        if (__shfl((int)q.is_align, (int)(row * 16u + k))) total = (total + 0x7fffull) & ~0x7fffull;  // align(), :679-684
+      }
+      acc = j == 0 ? total : 0ull;
+    } else {
+      acc += cost;
+    }
+  }
+  const uint64_t total = row_sum64(acc);
+  const uint64_t bad_mask = __ballot(bad != 0);
+  if (live && j == 0) {
+    frac_bits[sub] = total;
+    if (flags) flags[sub] = ((bad_mask >> (row * 16u)) & 0xffffull) ? CABAC_RES_BAD_RECORD : 0u;
+  }
+}
+
+hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t *frac_bits, uint32_t *flags) {
+  if (n_sub == 0) return hipSuccess;
+  const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
+  // two waves per SIMD run side by side at full speed (see the cost model): prefer many single-wave workgroups
+  hipLaunchKernelGGL(estimate_kernel<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, frac_bits, flags);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

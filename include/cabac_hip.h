@@ -167,6 +167,19 @@ int cabac_hip_decode_device(cabac_hip_ctx *ctx, uint32_t n_sub,
                             const uint8_t *d_bytes, uint8_t *d_bins,
                             cabac_substream_result *d_results);
 
+/* Bit estimator.  Replace: TBitEstimator::encodeBin / BitEstimatorBase::encodeBinEP /
+ * encodeBinTrm / align / reset / getEstFracBits (arith_codec.cpp:603-711) with
+ * BinProbModel_Std::estFracBitsUpdate / estFracBitsTrm and the m_binFracBits table
+ * (contexts.cpp:791-878, :922-937) for a batch of n_sub bin strings: d_frac_bits[s]
+ * receives the cost of substream s in 1/32768 bit (SCALE_BITS = 15) after
+ * reset(qp, init_id & 3); only rec_offset, n_records, qp and init_id of the
+ * descriptor are used.  d_flags (may be NULL) receives CABAC_RES_BAD_RECORD or 0;
+ * the cost of a substream with a bad record is unspecified.  encodeBinsEP /
+ * encodeRemAbsEP cost one bit per bypass bin they expand to (:640-677).        */
+int cabac_hip_estimate_device(cabac_hip_ctx *ctx, uint32_t n_sub,
+                              const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                              uint64_t *d_frac_bits, uint32_t *d_flags);
+
 /* Context-store initialisation only (Ctx::init, contexts.cpp:893-901, :915-920,
  * :996-1015): d_state[(s*379 + k)] = s0 | s1 << 16, d_rate[...] = m_rate for
  * substream s = (qp[s], init_id[s]).  Used by parity tests.                  */
@@ -207,10 +220,10 @@ int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
                            uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
 
 /* ---- per-launch timing (HIP events on the ctx stream) ----------------
- * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize device call is
+ * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize/estimate device call is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
  * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
- * (0 encode, 1 decode, 2 binarize, 3 ctx_init) and ms[i] for the recorded calls in launch order,
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate) and ms[i] for the recorded calls in launch order,
  * returns their number and resets the ring.                                 */
 int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
 int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);
