@@ -25,7 +25,7 @@ EXPORTS = [
     "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
-    "cabac_hip_estimate_device",
+    "cabac_hip_estimate_device", "cabac_hip_estimate_batch",
 ]
 
 _lib = None
@@ -70,6 +70,7 @@ def load_library():
     L.cabac_hip_split_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_count_emulations_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_estimate_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
+    L.cabac_hip_estimate_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.cabac_synth_records.restype = None
@@ -183,20 +184,16 @@ class CabacHip:
         self._check(self.L.cabac_hip_estimate_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_frac_bits),
                                                      vp(d_flags) if d_flags else None))
 
-    def estimate_batch(self, desc, records):
-        """Host-array convenience over estimate_device (torch tensors as staging): (frac_bits, flags)."""
-        import torch
+    def estimate_batch(self, desc, records, check=False):
+        """Host arrays through cabac_hip_estimate_batch: (frac_bits uint64[n], flags uint32[n])."""
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         records = np.ascontiguousarray(records, np.uint16)
-        dev = "cuda:%d" % self.device
-        t_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
-        t_rec = torch.from_numpy(records.view(np.int16).copy() if len(records) else np.zeros(1, np.int16)).to(dev)
-        t_bits = torch.zeros(max(len(desc), 1), dtype=torch.int64, device=dev)
-        t_flags = torch.zeros(max(len(desc), 1), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize(dev)  # the staging copies ran on torch's stream, the kernel runs on the codec's
-        self.estimate_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), t_bits.data_ptr(), t_flags.data_ptr())
-        self.synchronize()
-        return (t_bits.cpu().numpy().view(np.uint64)[: len(desc)], t_flags.cpu().numpy().view(np.uint32)[: len(desc)])
+        bits = np.zeros(max(len(desc), 1), np.uint64)
+        flags = np.zeros(max(len(desc), 1), np.uint32)
+        rc = self.L.cabac_hip_estimate_batch(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
+                                             bits.ctypes.data, flags.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return bits[: len(desc)], flags[: len(desc)]
 
     def binarize_device(self, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records):
         self._check(self.L.cabac_hip_binarize_device(self.h, n_sub, vp(d_se_offset), vp(d_se), vp(d_rec_offset),

@@ -344,6 +344,39 @@ int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   return status;
 }
 
+int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                             uint64_t n_records_total, uint64_t *frac_bits, uint32_t *flags) {
+  if (!c || (n_sub && (!desc || !frac_bits))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (n_sub == 0) return CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    if (desc[s].rec_offset + desc[s].n_records > n_records_total) return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if ((desc[s].init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
+  }
+  DeviceGuard g(c->device);
+  int rc;
+  if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
+  if ((rc = ensure(c, 3, n_sub * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, 4, n_sub * sizeof(uint32_t)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
+  if (n_records_total)
+    HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], records, n_records_total * 2, hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_estimate_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint16_t *)c->d_buf[1],
+                                 (uint64_t *)c->d_buf[3], (uint32_t *)c->d_buf[4]);
+  if (rc) return rc;
+  std::vector<uint32_t> fl(n_sub);
+  HIP_TRY(c, hipMemcpyAsync(frac_bits, c->d_buf[3], n_sub * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(fl.data(), c->d_buf[4], n_sub * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int status = CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    if (flags) flags[s] = fl[s];
+    if (fl[s]) status = CABAC_HIP_ERR_SUBSTREAM;
+  }
+  if (status) c->last_error = "substream flag set (see flags[])";
+  return status;
+}
+
 int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                            uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
                            cabac_substream_result *results) {

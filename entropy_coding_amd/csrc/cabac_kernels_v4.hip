@@ -194,6 +194,7 @@ struct QuadRecord {  // one bin record of a 16-bin step, with the context state 
   bool is_ctx, is_ep, is_trm, is_align;
 };
 
+template <uint32_t kLowestSpecial = CABAC_REC_ALIGN>  // ids from here up to 0x1FF are not "bad" (the estimator has two more)
 __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
                                                    uint32_t &bad) {
   QuadRecord q;
@@ -203,7 +204,7 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
   const bool is_ep = active && id == CABAC_REC_EP;
   const bool is_trm = active && id == CABAC_REC_TRM;
   const bool is_align = active && id == CABAC_REC_ALIGN;
-  if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+  if (active && !is_ctx && id < kLowestSpecial) bad = 1;
   const uint32_t j = lane & 15u;
   const uint32_t same = (uint32_t)(match_any_bits<9>(id, 0xffffull << (16u * row)) >> (16u * row)) & 0xffffu;
   const uint32_t binmask = (uint32_t)(__ballot(bin != 0) >> (16u * row)) & 0xffffu;  // the bins of this row
@@ -865,16 +866,22 @@ __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const 
   for (uint32_t base = 0; base < max_n; base += 16) {
     const uint32_t r = next_rec;
     next_rec = rec_safe[min(base + 16u + j, last_rec)];
-    const QuadRecord q = quad_resolve(r, base + j < n, lane, row, rctx, bad);
+    const QuadRecord q = quad_resolve<CABAC_REC_EST_RESTART>(r, base + j < n, lane, row, rctx, bad);
+    const bool active = base + j < n;
+    const bool zero = active && q.id == CABAC_REC_EST_RESETBITS, whole = active && q.id == CABAC_REC_EST_RESTART;
     uint32_t cost = 0;
     if (q.is_ctx) cost = frac[2u * ctx2_q8(q.st) + q.bin];
     if (q.is_ep) cost = 1u << 15;                     // estFracBitsEP, contexts.cpp:880-882
     if (q.is_trm) cost = q.bin ? 0x3bfbbu : 0x0010cu;  // estFracBitsTrm, contexts.cpp:931-933
-    if (__builtin_expect(__ballot(q.is_align) != 0, 0)) {
+    const uint32_t special = q.is_align ? 1u : zero ? 2u : whole ? 3u : 0u;  // records that need the total in order
+    if (__builtin_expect(__ballot(special != 0) != 0, 0)) {
       uint64_t total = row_sum64(acc);  // everything before this step
       for (int k = 0; k < 16; k++) {
         total += (uint32_t)__shfl((int)cost, (int)(row * 16u + k));
-        if (__shfl((int)q.is_align, (int)(row * 16u + k))) total = (total + 0x7fffull) & ~0x7fffull;  // align(), :679-684
+        const int what = __shfl((int)special, (int)(row * 16u + k));
+        if (what == 1) total = (total + 0x7fffull) & ~0x7fffull;  // align(), arith_codec.cpp:679-684
+        if (what == 2) total = 0;                                   // resetBits() / start(), :615, :628
+        if (what == 3) total &= ~0x7fffull;                         // restart(), :619-621
       }
       acc = j == 0 ? total : 0ull;
     } else {

@@ -162,6 +162,28 @@ void HipBatch::flush() {
   }
 }
 
+std::vector<uint64_t> HipBatch::estimate(const std::vector<EstimateJob> &jobs) {
+  const uint32_t n = uint32_t(jobs.size());
+  std::vector<uint64_t> cost(n, 0);
+  if (n == 0) return cost;
+  std::vector<cabac_substream_desc> desc(n);
+  uint64_t rec_total = 0;
+  for (uint32_t s = 0; s < n; s++) {
+    desc[s] = cabac_substream_desc{};
+    desc[s].rec_offset = rec_total;
+    desc[s].n_records = jobs[s].n_records;
+    desc[s].qp = jobs[s].qp;
+    desc[s].init_id = uint32_t(jobs[s].initId);
+    rec_total += jobs[s].n_records;
+  }
+  std::vector<uint16_t> records(rec_total ? rec_total : 1);
+  for (uint32_t s = 0; s < n; s++)
+    if (jobs[s].n_records) std::memcpy(records.data() + desc[s].rec_offset, jobs[s].records, size_t(jobs[s].n_records) * 2);
+  const int rc = cabac_hip_estimate_batch(handle(), n, desc.data(), records.data(), rec_total, cost.data(), nullptr);
+  check_status(m_ctx, rc, "cabac_hip_estimate_batch");
+  return cost;
+}
+
 void HipBatch::decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
                       std::vector<uint32_t> *bitsRead) {
   const uint32_t n = uint32_t(jobs.size());
@@ -225,6 +247,55 @@ void BinEncoderHip::reset(int qp, int initId) {
 void BinEncoderHip::resetBits() {
   if (!m_records.empty()) fail("resetBits(): bins already recorded for this substream");
   BinCounter::reset();
+}
+
+// ---- BitEstimatorHip ------------------------------------------------------------------------------------
+void BitEstimatorHip::reset(int qp, int initId) {  // Ctx::init + cost := 0, arith_codec.cpp:623-626
+  m_records.clear();
+  m_qp = qp;
+  m_initId = initId;
+  m_valid = true;
+  m_cached = 0;
+}
+
+uint64_t BitEstimatorHip::getEstFracBits() const {
+  if (!m_valid) {
+    HipBatch::EstimateJob job{m_records.data(), uint32_t(m_records.size()), m_qp, m_initId};
+    m_cached = m_batch.estimate({job})[0];
+    m_valid = true;
+  }
+  return m_cached;
+}
+
+void BitEstimatorHip::encodeBin(unsigned bin, unsigned ctxId) {
+  if (ctxId >= CABAC_NUM_CONTEXTS) fail("ctxId out of range");
+  put(ctxId | (bin ? CABAC_REC_BIN : 0u));
+}
+
+void BitEstimatorHip::encodeBinsEP(unsigned, unsigned numBins) {  // arith_codec.cpp:640-642: numBins bits
+  for (unsigned i = 0; i < numBins; i++) put(CABAC_REC_EP);
+}
+
+void BitEstimatorHip::encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) {
+  // arith_codec.cpp:653-677: the length of the code word in bits
+  const unsigned threshold = cutoff << goRicePar;
+  unsigned nbits;
+  if (bins < threshold) {
+    nbits = (bins >> goRicePar) + 1 + goRicePar;
+  } else {
+    const unsigned maxPrefixLength = 32 - cutoff - unsigned(maxLog2TrDynamicRange);
+    unsigned prefixLength = 0, suffixLength;
+    const unsigned codeValue = (bins >> goRicePar) - cutoff;
+    if (codeValue >= ((1u << maxPrefixLength) - 1)) {
+      prefixLength = maxPrefixLength;
+      suffixLength = unsigned(maxLog2TrDynamicRange);
+    } else {
+      while (codeValue > ((2u << prefixLength) - 2u)) prefixLength++;
+      suffixLength = prefixLength + goRicePar + 1;
+    }
+    nbits = cutoff + prefixLength + suffixLength;
+  }
+  for (unsigned i = 0; i < nbits; i++) put(CABAC_REC_EP);
 }
 
 void BinEncoderHip::encodeBin(unsigned bin, unsigned ctxId) {

@@ -124,6 +124,17 @@ public:
   void decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
               std::vector<uint32_t> *bitsRead = nullptr);
 
+  // Bit estimator: the cost (1/32768 bit) of each bin string after reset(qp, initId), one launch for all
+  // (BitEstimator_Std, arith_codec.cpp:603-711).  Strings may contain the estimator pseudo-records
+  // CABAC_REC_EST_RESETBITS / CABAC_REC_EST_RESTART (cabac_hip.h).
+  struct EstimateJob {
+    const uint16_t *records;
+    uint32_t n_records;
+    int qp;
+    int initId;
+  };
+  std::vector<uint64_t> estimate(const std::vector<EstimateJob> &jobs);
+
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
   // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned
@@ -215,6 +226,49 @@ private:
   OutputBitstream *m_Bitstream = nullptr;
   std::vector<uint16_t> m_records;
   int m_qp = 0, m_initId = 0;
+};
+
+// Recording bit estimator with the interface of the reference's BitEstimator_Std (arith_codec.hpp:159-213).
+// The calls since reset(qp, initId) are kept as bin records (resetBits() / start() / restart() as pseudo-records,
+// so that contexts carry on exactly as in the reference); getEstFracBits() has them costed on the device in one
+// launch and caches the answer until the next call that changes it.  For many candidate strings use
+// HipBatch::estimate on records() — one launch for all.
+class BitEstimatorHip : public BinEncIf {
+public:
+  explicit BitEstimatorHip(HipBatch &batch) : m_batch(batch) {}
+  void init(OutputBitstream *) override {}                 // arith_codec.cpp:611
+  void uninit() override {}                                // :613
+  void start() override { put(CABAC_REC_EST_RESETBITS); }  // :615
+  void finish() override {}                                // :617
+  void restart() override { put(CABAC_REC_EST_RESTART); }  // :619-621
+  void reset(int qp, int initId) override;                 // :623-626
+  void resetBits() override { put(CABAC_REC_EST_RESETBITS); }  // :628
+  uint64_t getEstFracBits() const override;                // :630
+  unsigned getNumBins(unsigned) const override { throw Exception("not supported for BitEstimator"); }  // :632-635
+  void encodeBin(unsigned bin, unsigned ctxId) override;
+  void encodeBinEP(unsigned bin) override { put(CABAC_REC_EP | (bin ? CABAC_REC_BIN : 0u)); }
+  void encodeBinsEP(unsigned bins, unsigned numBins) override;
+  void encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) override;
+  void encodeBinTrm(unsigned bin) override { put(CABAC_REC_TRM | (bin ? CABAC_REC_BIN : 0u)); }
+  void align() override { put(CABAC_REC_ALIGN); }
+  uint32_t getNumBins() override { throw Exception("Not supported"); }  // :644-647
+  bool isEncoding() override { return false; }                           // :651
+  unsigned getNumWrittenBits() override { return 0; }                    // :649
+
+  const std::vector<uint16_t> &records() const { return m_records; }
+  int qp() const { return m_qp; }
+  int initId() const { return m_initId; }
+
+private:
+  void put(unsigned rec) {
+    m_records.push_back(uint16_t(rec));
+    m_valid = false;
+  }
+  HipBatch &m_batch;
+  std::vector<uint16_t> m_records;
+  int m_qp = 0, m_initId = 0;
+  mutable bool m_valid = true;
+  mutable uint64_t m_cached = 0;
 };
 
 // ---------------------------------------------------------------------------------------------

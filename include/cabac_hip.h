@@ -44,6 +44,10 @@ extern "C" {
  *              0x1FE = bypass bin   (encodeBinEP,  arith_codec.cpp:389-399)
  *              0x1FF = terminate bin(encodeBinTrm, arith_codec.cpp:460-478)
  *              0x1FD = align(): range := 256 (arith_codec.cpp:480); codes no bin
+ *              0x1FC, 0x1FB = bit-estimator pseudo-records (cabac_hip_estimate_* only; a bad
+ *                  record for the codec): resetBits() / start() — the running cost := 0 — and
+ *                  restart() — the running cost rounded DOWN to a whole bit
+ *                  (arith_codec.cpp:615-628); contexts carry on
  * encodeBinsEP / encodeRemAbsEP (arith_codec.cpp:401-458) are recorded as their
  * individual bypass bins, MSB first — byte-identical by construction (the
  * reference's 8-at-a-time loop is arithmetically n single bypass bins).
@@ -51,6 +55,8 @@ extern "C" {
 #define CABAC_REC_BIN 0x8000u
 #define CABAC_REC_ID_MASK 0x01FFu
 #define CABAC_REC_ALIGN 0x01FDu
+#define CABAC_REC_EST_RESETBITS 0x01FCu
+#define CABAC_REC_EST_RESTART 0x01FBu
 #define CABAC_REC_EP 0x01FEu
 #define CABAC_REC_TRM 0x01FFu
 
@@ -218,6 +224,12 @@ int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
 int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
                            const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
                            uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
+
+/* Host-pointer form of cabac_hip_estimate_device (synchronous).  flags may be NULL;
+ * returns CABAC_HIP_ERR_SUBSTREAM if any substream had a bad record.            */
+int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                             const uint16_t *records, uint64_t n_records_total,
+                             uint64_t *frac_bits, uint32_t *flags);
 
 /* ---- per-launch timing (HIP events on the ctx stream) ----------------
  * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize/estimate device call is

@@ -858,6 +858,10 @@ static int estimate_record_run(ctx_store *c, const uint16_t *rec, long n, uint64
     } else if (id == CABAC_REC_ALIGN) {
       const uint64_t add = (1u << ORC_SCALE_BITS) - 1; /* align(), arith_codec.cpp:679-684 */
       b = (b + add) & ~add;
+    } else if (id == CABAC_REC_EST_RESETBITS) {
+      b = 0; /* resetBits() / start(), arith_codec.cpp:615, :628 */
+    } else if (id == CABAC_REC_EST_RESTART) {
+      b = (b >> ORC_SCALE_BITS) << ORC_SCALE_BITS; /* restart(), :619-621 */
     } else {
       return -2;
     }

@@ -355,6 +355,8 @@ int ref_estimate_records(const uint16_t *rec, long n, int qp, int initId, uint64
       else if (id == 0x1fe) e.encodeBinEP(bin);
       else if (id == 0x1ff) e.encodeBinTrm(bin);
       else if (id == 0x1fd) e.align();
+      else if (id == 0x1fc) { if (i & 1) e.resetBits(); else e.start(); }  // both zero the cost, nothing else
+      else if (id == 0x1fb) e.restart();
       else { strcpy(g_err, "bad record"); return -2; }
     }
     *frac_bits = est.getEstFracBits();

@@ -147,4 +147,54 @@ long shim_bitstream_writes(const uint32_t *vals, const uint32_t *nbits, long n, 
     return -1;
   }
 }
+// BitEstimatorHip driven like the reference drives BitEstimator_Std in RDO: the op stream is applied in
+// `n_seg` segments; before segment i (i > 0) resetBits() (seg_kind 0), start() (1) or restart() (2) is
+// called and the cost read with getEstFracBits() — costs[i] = the value read at the end of segment i.
+// record_only != 0: no device call; rec receives the recorded records (returns their number).
+long shim_estimate_segments(const uint32_t *ops, const long *seg_end, const int *seg_kind, int n_seg, int qp, int initId,
+                            uint64_t *costs, int record_only, uint16_t *rec, long cap) {
+  try {
+    HipBatch batch(0);
+    BitEstimatorHip est(batch);
+    est.reset(qp, initId);
+    long begin = 0;
+    for (int i = 0; i < n_seg; i++) {
+      if (i > 0) {
+        if (seg_kind[i] == 0) est.resetBits();
+        else if (seg_kind[i] == 1) est.start();
+        else est.restart();
+      }
+      apply_ops(est, ops + 4 * begin, seg_end[i] - begin);
+      begin = seg_end[i];
+      if (!record_only) costs[i] = est.getEstFracBits();
+    }
+    const std::vector<uint16_t> &r = est.records();
+    if (rec) {
+      if ((long)r.size() > cap) return -3;
+      if (!r.empty()) memcpy(rec, r.data(), r.size() * 2);
+    }
+    return (long)r.size();
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
 }
+
+// many recordings, one launch (HipBatch::estimate)
+int shim_estimate_many(const uint16_t *records, const long *rec_off, int n, const int *qp, const int *initId,
+                       uint64_t *costs) {
+  try {
+    HipBatch batch(0);
+    std::vector<HipBatch::EstimateJob> jobs;
+    for (int i = 0; i < n; i++)
+      jobs.push_back({records + rec_off[i], uint32_t(rec_off[i + 1] - rec_off[i]), qp[i], initId[i]});
+    const std::vector<uint64_t> c = batch.estimate(jobs);
+    for (int i = 0; i < n; i++) costs[i] = c[i];
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+} // extern "C"

@@ -44,6 +44,15 @@ def test_estimate_records_matches_reference():
     # one context hammered (state saturates both ways), and align records in between
     rec = np.array([7 | 0x8000] * 300 + [0x1FD] + [7] * 300 + [0x1FE, 0x1FD, 0x81FF], np.uint16)
     assert orc.estimate_records(rec, 30, 2) == ref.estimate_records(rec, 30, 2)
+    # resetBits() / start() (cost := 0) and restart() (cost rounded down to a whole bit) in between; contexts carry on
+    for seed in range(4):
+        r2 = np.random.default_rng(9200 + seed)
+        rec = H.random_records(r2, 3000, ctx_frac=0.7)
+        pos = r2.integers(0, 3000, size=40)
+        rec[pos[:15]] = 0x1FC
+        rec[pos[15:30]] = 0x1FB
+        rec[pos[30:]] = 0x1FD
+        assert orc.estimate_records(rec, 27, seed % 3) == ref.estimate_records(rec, 27, seed % 3)
     bad = np.array([3, 0x1F0, 4], np.uint16)
     assert orc.estimate_records(bad, 30, 2)[0] == -2 and ref.estimate_records(bad, 30, 2)[0] == -2
 

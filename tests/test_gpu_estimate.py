@@ -20,9 +20,9 @@ def _batch(rng, lens, ctx_fracs, with_align=True):
     recs = []
     for n, f in zip(lens, ctx_fracs):
         r = H.random_records(rng, n - 1, ctx_frac=f) if n > 0 else np.zeros(0, np.uint16)
-        if with_align and n > 40:  # sprinkle align() records: the running total is rounded up to a whole bit
-            pos = rng.integers(0, n - 1, size=max(1, n // 200))
-            r[pos] = 0x1FD
+        if with_align and n > 40:  # sprinkle align() / resetBits() / restart(): they act on the running total
+            pos = rng.integers(0, n - 1, size=max(3, n // 100))
+            r[pos] = rng.choice([0x1FD, 0x1FC, 0x1FB], size=len(pos))
         recs.append(r)
     records = np.concatenate(recs) if recs else np.zeros(0, np.uint16)
     lens = [len(r) for r in recs]

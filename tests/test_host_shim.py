@@ -36,6 +36,11 @@ def drv():
     L.shim_encode_streams.argtypes = [ctypes.c_int, u32p, lp, ip, ip, ctypes.c_int, ctypes.c_int, u8p, lp, u32p]
     L.shim_decode_replay.argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_long,
                                      ctypes.c_int, u8p, u32p]
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.shim_estimate_segments.restype = ctypes.c_long
+    L.shim_estimate_segments.argtypes = [u32p, lp, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, ctypes.c_int, u16p,
+                                         ctypes.c_long]
+    L.shim_estimate_many.argtypes = [u16p, lp, ctypes.c_int, ip, ip, u64p]
     L.shim_bitstream_writes.restype = ctypes.c_long
     L.shim_bitstream_writes.argtypes = [u32p, u32p, ctypes.c_long, ctypes.c_int, u8p, ctypes.c_long, u32p]
     return L
@@ -163,3 +168,79 @@ def test_shim_decode_replay(drv):
     rc = drv.shim_decode_replay(H._ptr(rec, u16p), len(rec), 27, 2, H._ptr(buf, u8p), len(data) // 2, 1,
                                 H._ptr(bins, u8p), ctypes.byref(idx))
     assert rc == -1 and b"FIFO exceeded" in drv.shim_last_error()
+
+
+# ---- bit estimator shim (BitEstimatorHip / HipBatch::estimate) ----------------------------------------
+def _segments(rng, n_ops, n_seg):
+    ends = np.sort(rng.integers(0, n_ops + 1, size=n_seg - 1)).tolist() + [n_ops]
+    kinds = [0] + [int(k) for k in rng.integers(0, 3, size=n_seg - 1)]
+    return np.array(ends, np.int64), np.array(kinds, np.int32)
+
+
+def test_estimator_recorder_matches_reference_semantics(drv):
+    """CPU: what BitEstimatorHip records (pseudo-records for resetBits / start / restart included), costed by the
+    oracle, equals the reference's BitEstimator_Std driven with the same calls."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(610)
+    for _ in range(6):
+        ops = H.random_ops(rng, 800, ctx_frac=0.7, with_align=True)
+        ends, kinds = _segments(rng, len(ops), 6)
+        rec = np.zeros(40 * len(ops) + 64, np.uint16)
+        n = drv.shim_estimate_segments(H._ptr(ops, u32p), ends.ctypes.data_as(lp), kinds.ctypes.data_as(ip), len(ends),
+                                       31, 2, None, 1, H._ptr(rec, u16p), len(rec))
+        assert n >= 0, drv.shim_last_error()
+        rec = rec[:n]
+        # the same calls on the oracle: the op segments expanded to records, pseudo-records in between
+        want, begin = [], 0
+        for e, k in zip(ends, kinds):
+            if begin or len(want):
+                pass
+            seg = orc.ops_to_records(ops[begin:e]) if e > begin else np.zeros(0, np.uint16)
+            want.append((k, seg))
+            begin = int(e)
+        parts = []
+        for i, (k, seg) in enumerate(want):
+            if i > 0:
+                parts.append(np.array([0x1FB if k == 2 else 0x1FC], np.uint16))
+            parts.append((seg & 0x81FF).astype(np.uint16))
+        flat = np.concatenate(parts)
+        # the estimator records bypass bins without their values (their cost does not depend on them)
+        ep = (flat & 0x1FF) == 0x1FE
+        got_ep = (rec & 0x1FF) == 0x1FE
+        assert len(rec) == len(flat) and np.array_equal(ep, got_ep)
+        assert np.array_equal(rec[~got_ep], flat[~ep])
+        assert orc.estimate_records(rec, 31, 2) == orc.estimate_records(flat, 31, 2)
+        if H.ref_available():
+            assert H.load_ref().estimate_records(flat, 31, 2) == orc.estimate_records(rec, 31, 2)
+
+
+@pytest.mark.gpu
+def test_estimator_shim_on_gpu(drv):
+    """GPU: getEstFracBits() after every segment equals the oracle's running value; HipBatch::estimate in bulk."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(611)
+    ops = H.random_ops(rng, 1500, ctx_frac=0.6, with_align=True)
+    ends, kinds = _segments(rng, len(ops), 5)
+    costs = np.zeros(len(ends), np.uint64)
+    rec = np.zeros(40 * len(ops) + 64, np.uint16)
+    n = drv.shim_estimate_segments(H._ptr(ops, u32p), ends.ctypes.data_as(lp), kinds.ctypes.data_as(ip), len(ends), 22, 1,
+                                   costs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 0, H._ptr(rec, u16p), len(rec))
+    assert n >= 0, drv.shim_last_error()
+    rec = rec[:n]
+    # prefix of the recording up to the end of each segment = everything before the next pseudo-record
+    cuts = [i for i, r in enumerate(rec) if (r & 0x1FF) in (0x1FB, 0x1FC)] + [len(rec)]
+    assert len(cuts) == len(ends)
+    for i, c in enumerate(cuts):
+        assert orc.estimate_records(rec[:c], 22, 1) == (0, int(costs[i])), i
+    # bulk: 50 candidate strings, one launch
+    recs = [H.random_records(rng, int(rng.integers(0, 400)), ctx_frac=0.7) for _ in range(50)]
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.int64)
+    qps = rng.integers(0, 64, size=50).astype(np.int32)
+    ids = rng.integers(0, 3, size=50).astype(np.int32)
+    out = np.zeros(50, np.uint64)
+    allrec = np.concatenate(recs + [np.zeros(1, np.uint16)])
+    rc = drv.shim_estimate_many(H._ptr(allrec, u16p), off.ctypes.data_as(lp), 50, qps.ctypes.data_as(ip),
+                                ids.ctypes.data_as(ip), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    assert rc == 0, drv.shim_last_error()
+    for i in range(50):
+        assert orc.estimate_records(recs[i], int(qps[i]), int(ids[i])) == (0, int(out[i]))
