@@ -119,5 +119,49 @@ private:
   int m_qp = 0, m_initId = 0;
 };
 
+// BitEstimatorHipRef IS-A EntropyCoding::BinEncIf with the behaviour of the reference's BitEstimator_Std
+// (arith_codec.hpp:159-213): the reference's CABACWriter runs on it unchanged, the calls are recorded
+// (resetBits() / start() / restart() as pseudo-records, so contexts carry on as in the reference) and
+// getEstFracBits() has the recording costed on the device.  Bulk: HipBatch::estimate over records().
+class BitEstimatorHipRef : public EntropyCoding::BinEncIf {
+public:
+  explicit BitEstimatorHipRef(HipBatch &batch)
+      : EntropyCoding::BinEncIf(static_cast<const Common::BinProbModel_Std *>(nullptr)), m_est(batch) {}
+  void init(Common::OutputBitstream *) override {}
+  void uninit() override {}
+  void start() override { m_est.start(); }
+  void finish() override {}
+  void restart() override { m_est.restart(); }
+  void reset(int qp, int initId) override {
+    Common::Ctx::init(qp, initId);  // host-visible context store / GRAdaptStats as the reference has them
+    m_est.reset(qp, initId);
+  }
+  void resetBits() override { m_est.resetBits(); }
+  uint64_t getEstFracBits() const override { return m_est.getEstFracBits(); }
+  unsigned getNumBins(unsigned) const override { HIPREF_THROW("not supported for BitEstimator"); }
+  void encodeBin(unsigned bin, unsigned ctxId) override {
+    HIPREF_CHECK(ctxId >= CABAC_NUM_CONTEXTS, "ctxId out of range");
+    m_est.encodeBin(bin, ctxId);
+  }
+  void encodeBinEP(unsigned bin) override { m_est.encodeBinEP(bin); }
+  void encodeBinsEP(unsigned bins, unsigned numBins) override { m_est.encodeBinsEP(bins, numBins); }
+  void encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) override {
+    m_est.encodeRemAbsEP(bins, goRicePar, cutoff, maxLog2TrDynamicRange);
+  }
+  void encodeBinTrm(unsigned bin) override { m_est.encodeBinTrm(bin); }
+  void align() override { m_est.align(); }
+  uint32_t getNumBins() override { HIPREF_THROW("Not supported"); }
+  bool isEncoding() override { return false; }
+  unsigned getNumWrittenBits() override { return 0; }
+  void setBinStorage(bool) override {}
+  const EntropyCoding::BinStore *getBinStore() const override { return nullptr; }
+  EntropyCoding::BinEncIf *getTestBinEncoder() const override { return nullptr; }
+
+  const std::vector<uint16_t> &records() const { return m_est.records(); }
+
+private:
+  BitEstimatorHip m_est;
+};
+
 }  // namespace EntropyCodingAMD
 #endif

@@ -30,6 +30,9 @@ def adp():
     L.adapter_encode.restype = ctypes.c_long
     L.adapter_encode.argtypes = [ctypes.c_int, H.u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, H.u8p, ctypes.c_long,
                                  H.u32p, H.u32p]
+    L.adapter_estimate.restype = ctypes.c_long
+    L.adapter_estimate.argtypes = [ctypes.c_int, H.u32p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     L.adapter_record.restype = ctypes.c_long
     L.adapter_record.argtypes = [H.u32p, ctypes.c_long, H.u16p, ctypes.c_long, H.u32p]
     return L
@@ -66,3 +69,24 @@ def test_reference_cabacwriter_on_gpu_encoder_is_bit_exact(adp, seed):
     ref_bytes, ref_bits, ref_bins = _enc(adp, 0, ops, qp, iid)     # reference encoder
     gpu_bytes, gpu_bits, gpu_bins = _enc(adp, 1, ops, qp, iid)     # GPU encoder behind the same interface
     assert ref_bits == gpu_bits and ref_bins == gpu_bins and np.array_equal(ref_bytes, gpu_bytes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_cabacwriter_on_gpu_estimator_matches_bitestimator_std(adp, seed):
+    """The reference's own CABACWriter driving BitEstimatorHipRef (recorded, costed on the GPU) reports the same
+    getEstFracBits() as on the reference's BitEstimator_Std — after every segment, with resetBits() / start() /
+    restart() in between and the contexts carrying on."""
+    rng = np.random.default_rng(880 + seed)
+    ops = H.random_ops(rng, 1200, ctx_frac=[0.5, 0.8, 0.3][seed], with_align=True)
+    ends = np.array(np.sort(rng.integers(0, len(ops) + 1, size=5)).tolist() + [len(ops)], np.int64)
+    kinds = np.array([0] + [int(k) for k in rng.integers(0, 3, size=5)], np.int32)
+    res = []
+    for which in (0, 1):
+        costs = np.zeros(len(ends), np.uint64)
+        rc = adp.adapter_estimate(which, H._ptr(ops, H.u32p), ends.ctypes.data_as(ctypes.POINTER(ctypes.c_long)),
+                                  kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(ends), 29, seed % 3,
+                                  costs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+        assert rc == 0, adp.adapter_last_error()
+        res.append(costs)
+    assert np.array_equal(res[0], res[1])
