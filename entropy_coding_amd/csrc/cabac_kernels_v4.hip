@@ -663,7 +663,11 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   // wrong results on gfx950 (bisected with the parity tests); v_mul_u32_u24 with DPP is fine.
   const uint32_t sr = __umul24(rm, row_bcast<I>(f.srmul));
   const uint32_t e = w.hi - sr;                                  // value - scaledRange; both are below 2^31
-  const uint32_t ngem = (uint32_t)((int32_t)e >> 31);            // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0
+  // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0.  Through asm so that hipcc sees an opaque mask: written
+  // as (int)e >> 31 it turns every use back into v_cmp + v_cndmask pairs, two instructions where a v_bfi /
+  // v_bitop3 on the mask is one.
+  uint32_t ngem;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(e));
   const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
   const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
   const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;          // getRenormBitsLPS; masked out when t == 0
