@@ -653,7 +653,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   }
   // the state of this bin's context, from the lane that holds the record; state() / getLPS, contexts.cpp:939-950
   const uint32_t st = row_bcast<I>(st_v);
-  const uint32_t sum = (st & kMask0) + (st >> 16);
+  const uint32_t sum = (st & 0xffffu) + (st >> 16);  // the low half carries no rate bits here (see the kernel)
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
   const uint32_t t = (__umul24(w.range >> 5, k) + row_bcast<I>(f.c2)) >> 1;
@@ -697,8 +697,9 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   const u16x2 st2 = __builtin_bit_cast(u16x2, st_v);
   const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, r0_v)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
-  const u16x2 bin2 = __builtin_bit_cast(u16x2, bin | (bin << 16));
-  uint32_t upd = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a_v) * bin2 + (st2 - dlt2)));
+  const uint32_t rest = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2));
+  uint32_t upd;  // both halves: rest + a * bin, the low half of `bin` feeding both lanes of the packed mad (op_sel_hi)
+  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(a_v), "v"(bin), "v"(rest));
   asm volatile("" : "+v"(upd));   // keep the update unconditional: hipcc would otherwise wrap it in an exec
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
@@ -722,10 +723,14 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
                                                            const uint16_t *__restrict__ records,
                                                            const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
                                                            cabac_substream_result *__restrict__ results) {
+  // decode keeps the two window sizes of a context (they never change) apart from its state word, whose low
+  // five bits are then zero: state() is one SDWA add of the two halves, without masking
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
+  __shared__ uint8_t rate_all[W * kQuadSubs * kQuadCtxStride];
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+  uint8_t *rrate = rate_all + (wave * kQuadSubs + row) * kQuadCtxStride;
   const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -736,8 +741,11 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   {
     const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
     const uint32_t iid = d.init_id & 3u;
-    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16)
-      rctx[k] = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16) {
+      const uint32_t packed = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
+      rctx[k] = packed & ~31u;
+      rrate[k] = (uint8_t)(packed & 31u);
+    }
   }
   __syncthreads();
 
@@ -773,9 +781,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
     const bool is_ctx = id < (uint32_t)kNumCtx;
     if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
-    const uint32_t stored = rctx[min(id, (uint32_t)kNumCtx)];  // slot kNumCtx is the row's pad word
+    const uint32_t slot = min(id, (uint32_t)kNumCtx);  // slot kNumCtx is the row's pad word
+    const uint32_t stored = rctx[slot], rates = rrate[slot];
     uint32_t st_v = is_ctx ? stored : 0u;
-    const uint32_t r0 = (st_v & 3u) + 2u, r1 = ((st_v >> 2) & 7u) + 5u;
+    const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
     const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
     const bool is_trm = active && id == CABAC_REC_TRM;
