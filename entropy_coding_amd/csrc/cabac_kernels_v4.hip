@@ -1,25 +1,27 @@
 // v4 "quad" kernels: FOUR substreams per wavefront, 16 lanes each, serial chain on the VECTOR pipe.
 //
-// Measured cost model of gfx950 (tools/ubench_issue.hip, tools/ubench_cross.hip): a wave issues one
-// instruction per ~4-5 cycles whether scalar or vector; a CU retires ~1 scalar + ~1 vector
-// instruction per cycle in total.  With one substream per wave (v1, v3) every instruction of the
-// serial low/range chain advances ONE bin, so a 4 096-substream batch is bound by instructions per
-// bin.  Here the four 16-lane rows of a wave carry four different substreams and the chain is written
-// with per-lane (row-uniform) vector arithmetic, so one instruction advances FOUR bins; the record of
-// step i is delivered to its row with a DPP row broadcast (v_mov_b32_dpp row_newbcast:i — one
-// instruction, no LDS, no scalar round trip).  Everything row-divergent is select-based; the only
-// branches are the rare ones (16-bit output flush, input refill).
+// Measured cost model of gfx950 (tools/ubench_*.hip): a wave issues one instruction per
+// ~4.4 cycles, scalar or vector, dependent or not; a SIMD executes one wave-wide integer instruction per
+// ~2.2 cycles (two waves per SIMD both run at full speed); a scalar instruction that consumes a vector
+// result stalls the wave ~55 cycles.  With one substream per wave (v1, v3) every instruction of the serial
+// low/range chain advances ONE bin.  Here the four 16-lane rows of a wave carry four different substreams and
+// the chain is written with per-lane (row-uniform) vector arithmetic, so one instruction advances FOUR bins;
+// the record of step i is delivered to its row with a DPP row broadcast (v_mov_b32_dpp row_newbcast:i — one
+// instruction, no LDS, no scalar round trip).  Everything row-divergent is mask arithmetic; the only
+// branches are the rare ones (output of whole 16-bit units, input refill).
 //
-//  encode: per 16-bin step  (a) the context states the 16 bins of each row see are resolved in
-//          parallel exactly as in v3 (match-any on ctxId|row, ds_bpermute rounds);  (b) 16 unrolled
-//          chain steps of ~27 vector instructions for the 4 rows together.
+//  encode: per 16-bin step  (a) quad_resolve: the context state each of the 16 bins of a row sees (match-any
+//          on ctxId, then every lane applies the earlier bins of its context itself);  (b) 16 unrolled
+//          chain steps of 23 vector instructions for the 4 rows together.  encode_kernel_v4 does both in one
+//          wave, encode_kernel_v5 in two (context wave / chain wave, see there).
 //          Byte output: `low` is kept as the exact code value and 16 bits are peeled off whenever 16
 //          have accumulated; the delayed carry of arith_codec.cpp:524-546 (buffered byte + count of
 //          outstanding 0xFF) is the same algorithm in base 2^16 (buffered unit + count of outstanding
 //          0xFFFF).  The emitted stream is the identical number: the top S+1 bits of low >> 8 with
 //          carries resolved (S = bits shifted), which is what finish() (:339-357) leaves.
-//  decode: the 64-bit look-ahead window of v2 per row; after each bin every lane applies it to its own
+//  decode: a 64-bit look-ahead window per row; after each bin every lane applies it to its own
 //          copy of the context state and the lanes of that row holding the same ctxId keep it.
+//  estimate: BitEstimator_Std on the same records — quad_resolve plus a table lookup, no chain.
 //
 // Layout: row r of wave w codes substream 4w + r.  Rows whose substreams are shorter idle at the end,
 // so batches should group substreams of similar length (cabac_hip.h: order is the caller's).
@@ -247,8 +249,7 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
 }
 
 __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                 uint64_t lt_mask, uint32_t &bad) {
-  (void)lt_mask;
+                                                 uint32_t &bad) {
   const QuadRecord q = quad_resolve(r, active, lane, row, rctx, bad);
   const uint32_t bin = q.bin;
   const uint32_t q8 = ctx2_q8(q.st);
@@ -333,12 +334,11 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
   e.cap = live ? d.byte_capacity : 0u;
   const bool writer = live && j == 0;
   uint32_t bad = 0;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
 
   uint32_t next_rec = j < n ? rec[j] : 0;
   for (uint32_t base = 0; __ballot(base < n) != 0; base += 16) {
     const uint32_t r = next_rec;  // loaded one step ago
-    const uint32_t info = quad_phase_a(r, base + j < n, lane, row, rctx, lt_mask, bad);
+    const uint32_t info = quad_phase_a(r, base + j < n, lane, row, rctx, bad);
     const QuadEncInfo f = quad_unpack(info);
     // prefetch the next 16 records of each row now: the load completes under the serial chain.  (Issued
     // any earlier, hipcc's s_waitcnt vmcnt(0) in front of the first use of `r` would wait for it too.)
@@ -506,14 +506,13 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     const bool writer = live && j == 0;
     uint32_t *list = unit_list[unit][row];
     uint32_t bad = 0;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
+      // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
     // past the end of a row they read a valid address and phase (a) ignores the value
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
-    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, lt_mask, bad);  // step 0
+    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
     __syncthreads();
     uint32_t slot = 1;
     QuadUnits units;
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
       V5_TICK(t2);
       // ... and prepare step base + 16
       next_rec = rec_safe[min(base + 32u + j, last_rec)];
-      const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, lt_mask, bad);
+      const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
       mail[slot][lane] = info;
       slot ^= 1u;
       V5_TICK(t3);
