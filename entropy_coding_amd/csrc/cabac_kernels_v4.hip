@@ -912,8 +912,11 @@ hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream
                            uint64_t *frac_bits, uint32_t *flags) {
   if (n_sub == 0) return hipSuccess;
   const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  // two waves per SIMD run side by side at full speed (see the cost model): prefer many single-wave workgroups
-  hipLaunchKernelGGL(estimate_kernel<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, frac_bits, flags);
+  // four-wave workgroups pin one wave per SIMD (see decode_kernel_v4); small batches spread single waves
+  if (waves >= 1024u)
+    hipLaunchKernelGGL(estimate_kernel<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, frac_bits, flags);
+  else
+    hipLaunchKernelGGL(estimate_kernel<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, frac_bits, flags);
   return hipGetLastError();
 }
 
@@ -928,11 +931,19 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results) {
   const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  static int upw = -1;  // pairs per workgroup; CABAC_V5_UNITS overrides for experiments
-  if (upw < 0) {
+  // Pairs per workgroup (CABAC_V5_UNITS overrides for experiments).  Four: the eight waves of a workgroup are dealt
+  // to the CU's four SIMDs in order, so that every SIMD gets one context wave and one chain wave whatever ran
+  // before.  Single-pair workgroups are a little faster when the dispatcher happens to spread them well (1.16
+  // against 1.20 ms on C4) but took 1.55 ms when the previous launch had another geometry, and 2.7 against 2.0 ms
+  // with 8 192 substreams.  (Replacing the barrier by per-pair LDS counters, so that the four pairs do not wait
+  // for each other, was tried and is slower: the polling wave takes issue slots from its partner.)
+  static int forced = -1;
+  if (forced < 0) {
     const char *e = getenv("CABAC_V5_UNITS");
-    upw = e ? atoi(e) : 1;
+    forced = e ? atoi(e) : 0;
   }
+  // fewer pairs than SIMD quads (256 CUs x 4 pairs): single-pair workgroups, so that they spread over all CUs
+  const int upw = forced ? forced : (units >= 1024u ? 4 : 1);
   if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(512), 0, st, n_sub, desc, records, bytes, results);
   else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(256), 0, st, n_sub, desc, records, bytes, results);
   else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(128), 0, st, n_sub, desc, records, bytes, results);
