@@ -445,15 +445,15 @@ __device__ __forceinline__ void quad_emit_units(QuadEnc &e, const QuadUnits &u, 
   e.pos += 2u * u.m;
 }
 
-// encode, TWO waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead, owns the LDS
-// context stores and writes the output; a chain wave runs the range / low recurrence and nothing else.
-// The two never wait on each other's memory: the hand-offs are one packed word per bin through a
-// double-buffered LDS mailbox (context -> chain), the posted (low, pend) of every 4th bin (chain -> context,
-// see QuadPost) and one workgroup barrier per 16-bin step.  A wave issues at most one instruction per ~4.4
-// cycles while a SIMD executes one per ~2.2 (tools/ubench_ilp.hip), so two waves per SIMD run side by side
-// at full speed and the kernel's time is the longer of the two instruction streams.
-// All pairs of a workgroup run the same number of steps (the longest substream's) so that the barrier
-// counts match; surplus steps are no-ops.
+// encode, THREE waves per 4 substreams ("v5"): a context wave runs phase (a) one step ahead and owns the LDS
+// context stores; a chain wave runs the range / low recurrence and nothing else; an output wave turns what the
+// chain wave posts into bytes.  They never wait on each other's memory: the hand-offs are one packed word per bin
+// through a double-buffered LDS mailbox (context -> chain), the posted (low, pend) of every 4th bin (chain ->
+// output, see QuadPost) and one workgroup barrier per 16-bin step.  A wave issues at most one instruction per
+// ~4.4 cycles while a SIMD executes one per ~2.2 (tools/ubench_ilp.hip): the chain wave (~420 instructions per
+// step, raised priority) sets the pace, and the other two (~170 and ~100) fit into the issue slots it cannot use.
+// All units of a workgroup run the same number of steps (the longest substream's) so that the barrier counts
+// match; surplus steps are no-ops.
 #ifdef CABAC_V5_PROFILE  // tools/ubench_v5.hip: where the two waves of workgroup 0 spend their cycles
 __device__ unsigned long long g_v5_prof[16];
 #define V5_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -465,7 +465,7 @@ __device__ unsigned long long g_v5_prof[16];
 #endif
 
 template <int U>
-__global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+__global__ __launch_bounds__(192 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                             const uint16_t *__restrict__ records,
                                                             uint8_t *__restrict__ bytes,
                                                             cabac_substream_result *__restrict__ results) {
@@ -474,9 +474,10 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
   __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];
   __shared__ uint32_t fin_lo[U][kQuadSubs], fin_hi[U][kQuadSubs], fin_pend[U][kQuadSubs];
   __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
+  __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
-  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave
+  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: output wave
   const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -490,23 +491,12 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
   const uint32_t max_n = wg_max_n;
 
   if (role == 0) {
-    // ---- context wave ------------------------------------------------------------------------
+    // ---- context wave: the fields of step base + 16 while the chain wave codes step base ----------
     const uint16_t *rec = records + d.rec_offset;
     uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
     quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
-    QuadEnc e;  // output state; low / pend are loaded from the chain wave's posts
-    e.low = 0;
-    e.range = 0;
-    e.pend = 0;
-    e.buf = 0;
-    e.nbuf = 0;
-    e.pos = 0;
-    e.dst = bytes + d.byte_offset;
-    e.cap = live ? d.byte_capacity : 0u;
-    const bool writer = live && j == 0;
-    uint32_t *list = unit_list[unit][row];
     uint32_t bad = 0;
-      // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
+    // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
     // past the end of a row they read a valid address and phase (a) ignores the value
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
@@ -515,57 +505,30 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
     mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
     __syncthreads();
     uint32_t slot = 1;
-    QuadUnits units;
-    units.m = 0;
-    units.odd_rows = 0;
-    units.store_lanes = 0;
-    bool listed = false;
     for (uint32_t base = 0; base < max_n; base += 16) {
-      // While the chain wave codes step `base`: write out the units listed one iteration ago (posted during step
-      // base - 32) and list what was posted during step base - 16.  Loads and stores share one counter (vmcnt), so
-      // a wait for the record load also waits for every store issued before it: the load is waited for first,
-      // then the stores are issued, then the next load — by the next iteration both are long done.
-      uint32_t r = next_rec;
-      asm volatile("" : "+v"(r));  // wait for the record load HERE, while no store is in flight (see above)
-      V5_TICK(t0);
-      if (listed) quad_emit_units(e, units, j, list, writer);
-      V5_TICK(t1);
-      listed = base != 0;
-      if (listed) units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
-      V5_TICK(t2);
-      // ... and prepare step base + 16
+      const uint32_t r = next_rec;
       next_rec = rec_safe[min(base + 32u + j, last_rec)];
+      V5_TICK(t2);
       const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
       mail[slot][lane] = info;
       slot ^= 1u;
       V5_TICK(t3);
       __syncthreads();
       V5_TICK(t4);
-      V5_ADD(0, t0, t1);  // emit
-      V5_ADD(1, t1, t2);  // list
       V5_ADD(2, t2, t3);  // phase (a)
       V5_ADD(3, t3, t4);  // waiting at the barrier
     }
-    __syncthreads();  // the chain wave has posted its last step and what it still holds
-    if (listed) quad_emit_units(e, units, j, list, writer);
-    if (max_n != 0) {
-      units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
-      quad_emit_units(e, units, j, list, writer);
-    }
-    e.low = ((uint64_t)fin_hi[unit][row] << 32) | fin_lo[unit][row];
-    e.pend = (int32_t)fin_pend[unit][row];
-    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
     const uint64_t bad_mask = __ballot(bad != 0);
-    const bool row_bad = ((bad_mask >> (row * 16u)) & 0xffffull) != 0;
-    if (writer) {
-      cabac_substream_result res;
-      res.n_bits = n_bits;
-      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (row_bad ? CABAC_RES_BAD_RECORD : 0u);
-      results[sub] = res;
+    if (lane == 0) {
+      uint32_t rows = 0;
+      for (uint32_t k = 0; k < 4; k++) rows |= ((bad_mask >> (16u * k)) & 0xffffull) ? (1u << k) : 0u;
+      bad_rows[unit] = rows;
     }
-  } else {
+    __syncthreads();
+  } else if (role == 1) {
     // ---- chain wave --------------------------------------------------------------------------
-    // its instruction stream is the longer one: let it win issue arbitration against the context wave
+    // its instruction stream is the longest: let it win issue arbitration against the two waves it shares
+    // its SIMD with
     __builtin_amdgcn_s_setprio(3);
     QuadEnc e;
     e.low = 0;
@@ -597,6 +560,54 @@ __global__ __launch_bounds__(128 * U) void encode_kernel_v5(uint32_t n_sub, cons
       fin_pend[unit][row] = (uint32_t)e.pend;
     }
     __syncthreads();
+  } else {
+    // ---- output wave: while the chain wave codes step base, write out the units listed one iteration ago
+    // (posted during step base - 32) and list what was posted during step base - 16 ----------------------
+    QuadEnc e;  // output state; low / pend are loaded from the chain wave's posts
+    e.low = 0;
+    e.range = 0;
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    uint32_t *list = unit_list[unit][row];
+    __syncthreads();
+    uint32_t slot = 1;
+    QuadUnits units;
+    units.m = 0;
+    units.odd_rows = 0;
+    units.store_lanes = 0;
+    bool listed = false;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      V5_TICK(t0);
+      if (listed) quad_emit_units(e, units, j, list, writer);
+      V5_TICK(t1);
+      listed = base != 0;
+      if (listed) units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
+      slot ^= 1u;
+      V5_TICK(t2);
+      __syncthreads();
+      V5_ADD(0, t0, t1);  // emit
+      V5_ADD(1, t1, t2);  // list
+    }
+    __syncthreads();  // the chain wave has posted its last step and what it still holds; bad_rows is written
+    if (listed) quad_emit_units(e, units, j, list, writer);
+    if (max_n != 0) {
+      units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
+      quad_emit_units(e, units, j, list, writer);
+    }
+    e.low = ((uint64_t)fin_hi[unit][row] << 32) | fin_lo[unit][row];
+    e.pend = (int32_t)fin_pend[unit][row];
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    if (writer) {
+      cabac_substream_result res;
+      res.n_bits = n_bits;
+      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
+      results[sub] = res;
+    }
   }
 }
 
@@ -931,8 +942,8 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results) {
   const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  // Pairs per workgroup (CABAC_V5_UNITS overrides for experiments).  Four: the eight waves of a workgroup are dealt
-  // to the CU's four SIMDs in order, so that every SIMD gets one context wave and one chain wave whatever ran
+  // Units (wave triples) per workgroup (CABAC_V5_UNITS overrides for experiments).  Four: the twelve waves of a
+  // workgroup are dealt to the CU's four SIMDs in order, so that every SIMD gets one wave of each kind whatever ran
   // before.  Single-pair workgroups are a little faster when the dispatcher happens to spread them well (1.16
   // against 1.20 ms on C4) but took 1.55 ms when the previous launch had another geometry, and 2.7 against 2.0 ms
   // with 8 192 substreams.  (Replacing the barrier by per-pair LDS counters, so that the four pairs do not wait
@@ -944,9 +955,9 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
   }
   // fewer pairs than SIMD quads (256 CUs x 4 pairs): single-pair workgroups, so that they spread over all CUs
   const int upw = forced ? forced : (units >= 1024u ? 4 : 1);
-  if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(512), 0, st, n_sub, desc, records, bytes, results);
-  else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(256), 0, st, n_sub, desc, records, bytes, results);
-  else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(128), 0, st, n_sub, desc, records, bytes, results);
+  if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
+  else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(384), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 
