@@ -621,6 +621,8 @@ struct QuadDec {   // row-uniform values
   uint32_t rp, nxt;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds it
   const uint8_t *src;
   uint32_t cap;
+  const uint8_t *src_safe;  // src, or any readable address for an empty substream
+  uint32_t last_dword;      // offset of the last dword that holds a byte of the substream
 };
 
 // Per-lane fields of one record for the decode chain.  A lane past the end of its substream carries the
@@ -637,6 +639,24 @@ struct QuadDecInfo {
   uint32_t key;   // ctxId of a context bin; a value unique in the row otherwise (so that it matches no other lane)
 };
 
+// Append one 16-bit unit to the window of every row that has fewer than 32 valid look-ahead bits: mask
+// arithmetic for all rows at once, no branch (the callers branch on scalar masks computed a step earlier).
+__device__ __forceinline__ void quad_dec_refill(QuadDec &w) {
+  const uint32_t take = neg_mask((uint32_t)w.look - 32u);
+  const uint32_t half = (w.nxt >> ((w.rp & 2u) << 3)) & 0xffffu;
+  const uint32_t unit = (((half & 0xffu) << 8) | (half >> 8)) & take;  // big-endian unit
+  const uint64_t add = (uint64_t)unit << ((31 - w.look) & 63);
+  w.hi |= (uint32_t)(add >> 32);
+  w.lo |= (uint32_t)add;
+  w.look += (int32_t)(16u & take);
+  w.rp += 2u & take;
+  // the dword that holds the next unit: reloaded when the pointer has crossed into a new one (an unconditional,
+  // aligned load from a clamped address; past the end of the substream the window is fed zeros)
+  const uint32_t crossed = take & neg_mask((w.rp & 2u) - 1u);
+  const uint32_t loaded = *reinterpret_cast<const uint32_t *>(w.src_safe + min(w.rp & ~3u, w.last_dword));
+  w.nxt = sel(crossed, w.rp < w.cap ? loaded : 0u, w.nxt);
+}
+
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
 // every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip.  The cost
 // of a step is its instruction count: a wave issues one instruction per ~4.4 cycles whether or not it
@@ -648,18 +668,16 @@ struct QuadDecInfo {
 template <int I, bool kSpecial>
 __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                               uint32_t &bits, QuadDec &w) {
-  // input check only every 4th bin (4 bins consume at most 28 bits): 16-bit units are appended while fewer
-  // than 32 look-ahead bits are valid, so that the three steps in between stay in one basic block
+  // Input check only every 4th bin (4 bins consume at most 24 bits): 16-bit units are appended while fewer than
+  // 32 look-ahead bits are valid.  The question is asked here, the answer acted upon at the END of this step: a
+  // branch right behind the compare would stall ~55 cycles, and the step in between cannot be hurt — a decision
+  // only depends on the nine bits of value that are compared with the range (window bits 62..54), and the
+  // look-ahead is never short of them by more than this one step's 6 bits below bit 47.
+  uint64_t refill = 0, refill2 = 0;
   if ((I & 3) == 0) {
-    while (__builtin_expect(w.look <= 31, 0)) {
-      const uint32_t half = (w.rp & 2u) ? (w.nxt >> 16) : (w.nxt & 0xffffu);
-      const uint64_t add = (uint64_t)(((half & 0xffu) << 8) | (half >> 8)) << (31 - w.look);  // big-endian unit
-      w.hi |= (uint32_t)(add >> 32);
-      w.lo |= (uint32_t)add;
-      w.look += 16;
-      w.rp += 2;
-      if ((w.rp & 2u) == 0u) w.nxt = w.rp < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + w.rp) : 0u;
-    }
+    refill = __ballot(w.look <= 31);
+    refill2 = __ballot(w.look <= 21);  // 15 + the 6 bits this step can consume: a second unit may be needed
+    asm volatile("" : "+s"(refill), "+s"(refill2));
   }
   // the state of this bin's context, from the lane that holds the record; state() / getLPS, contexts.cpp:939-950
   const uint32_t st = row_bcast<I>(st_v);
@@ -713,6 +731,10 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   asm volatile("" : "+v"(upd));   // keep the update unconditional: hipcc would otherwise wrap it in an exec
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
+  if ((I & 3) == 0 && refill != 0) {
+    quad_dec_refill(w);
+    if (refill2 != 0) quad_dec_refill(w);  // look >= 2 here, so two units always reach 32
+  }
 }
 
 template <bool kSpecial>
@@ -762,6 +784,8 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   QuadDec w;
   w.src = bytes + d.byte_offset;
   w.cap = live ? d.byte_capacity : 0u;
+  w.src_safe = w.cap != 0 ? w.src : reinterpret_cast<const uint8_t *>(desc);
+  w.last_dword = w.cap != 0 ? ((w.cap - 1u) & ~3u) : 0u;
   {
     // start(), arith_codec.cpp:60-66.  Input is read as aligned dwords that contain at least one valid byte
     // (cabac_hip.h: the bytes buffer is readable up to the next multiple of 4 past every substream).
