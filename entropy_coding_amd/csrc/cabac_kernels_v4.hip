@@ -618,7 +618,9 @@ struct QuadDec {   // row-uniform values
   uint32_t hi, lo;   // 64-bit window: value in [62:47] (see v2)
   int32_t look;
   uint32_t range;
-  uint32_t rp, nxt;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds it
+  uint32_t rp, nxt, nxt2, nxt3;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds
+                                 // it and the two after it
+  uint32_t pending, pvalid, pmask;  // the dword requested by the last check, whether it exists, who needs it
   const uint8_t *src;
   uint32_t cap;
   const uint8_t *src_safe;  // src, or any readable address for an empty substream
@@ -641,7 +643,19 @@ struct QuadDecInfo {
 
 // Append one 16-bit unit to the window of every row that has fewer than 32 valid look-ahead bits: mask
 // arithmetic for all rows at once, no branch (the callers branch on scalar masks computed a step earlier).
+// Input buffer: the three dwords from the one that holds the next unit (nxt, nxt2, nxt3).  A check appends at
+// most two units, so it crosses at most one dword boundary; the dword that then becomes the third is requested
+// by the first pass of the check (one unconditional, aligned load from a clamped address) and only looked at
+// by the NEXT check — no wait for memory anywhere near the chain.
+template <bool kFirstPass>
 __device__ __forceinline__ void quad_dec_refill(QuadDec &w) {
+  if (kFirstPass) {
+    w.nxt3 = sel(w.pmask, w.pending & w.pvalid, w.nxt3);  // the dword requested by the previous check
+    const uint32_t ahead = (w.rp & ~3u) + 12u;
+    w.pending = *reinterpret_cast<const uint32_t *>(w.src_safe + min(ahead, w.last_dword));
+    w.pvalid = neg_mask(ahead - w.cap);                   // past the end of the substream the window is fed zeros
+    w.pmask = 0;
+  }
   const uint32_t take = neg_mask((uint32_t)w.look - 32u);
   const uint32_t half = (w.nxt >> ((w.rp & 2u) << 3)) & 0xffffu;
   const uint32_t unit = (((half & 0xffu) << 8) | (half >> 8)) & take;  // big-endian unit
@@ -650,11 +664,10 @@ __device__ __forceinline__ void quad_dec_refill(QuadDec &w) {
   w.lo |= (uint32_t)add;
   w.look += (int32_t)(16u & take);
   w.rp += 2u & take;
-  // the dword that holds the next unit: reloaded when the pointer has crossed into a new one (an unconditional,
-  // aligned load from a clamped address; past the end of the substream the window is fed zeros)
   const uint32_t crossed = take & neg_mask((w.rp & 2u) - 1u);
-  const uint32_t loaded = *reinterpret_cast<const uint32_t *>(w.src_safe + min(w.rp & ~3u, w.last_dword));
-  w.nxt = sel(crossed, w.rp < w.cap ? loaded : 0u, w.nxt);
+  w.nxt = sel(crossed, w.nxt2, w.nxt);
+  w.nxt2 = sel(crossed, w.nxt3, w.nxt2);
+  w.pmask |= crossed;
 }
 
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
@@ -732,8 +745,8 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
   if ((I & 3) == 0 && refill != 0) {
-    quad_dec_refill(w);
-    if (refill2 != 0) quad_dec_refill(w);  // look >= 2 here, so two units always reach 32
+    quad_dec_refill<true>(w);
+    if (refill2 != 0) quad_dec_refill<false>(w);  // look >= 2 here, so two units always reach 32
   }
 }
 
@@ -796,6 +809,11 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   w.look = 16;
   w.rp = 4;
   w.nxt = 4u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 4) : 0u;
+  w.nxt2 = 8u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 8) : 0u;
+  w.nxt3 = 12u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 12) : 0u;
+  w.pending = 0;
+  w.pvalid = 0;
+  w.pmask = 0;
   w.range = 510;
   uint32_t bad = 0;
 
