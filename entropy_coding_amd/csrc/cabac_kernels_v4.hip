@@ -828,35 +828,38 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   const uint32_t last_rec = n != 0 ? n - 1u : 0u;
   uint32_t next_rec = rec_safe[min(j, last_rec)];
   for (uint32_t base = 0; base < max_n; base += 16) {
+    // The fields of this step's record, as 0 / ~0 masks from arithmetic: a boolean expression would become a lane
+    // mask in SGPRs, and every scalar instruction combining such masks waits ~55 cycles for the vector compare.
     const uint32_t r = next_rec;  // loaded one step ago
-    const bool active = base + j < n;
-    const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
-    const bool is_ctx = id < (uint32_t)kNumCtx;
-    if (active && !is_ctx && id < CABAC_REC_ALIGN) bad = 1;
+    const uint32_t actm = neg_mask(base + j - n);                        // ~0: a record of this substream
+    const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);        // past the end: an id that is nothing
+    const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
+    // asked first, needed last (the choice of the step variant): the branch finds the answer waiting
+    uint64_t special = __ballot((trm_m | aln_m) != 0);
+    asm volatile("" : "+s"(special));
+    const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);              // id < 379
+    bad |= actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
     const uint32_t slot = min(id, (uint32_t)kNumCtx);  // slot kNumCtx is the row's pad word
     const uint32_t stored = rctx[slot], rates = rrate[slot];
-    uint32_t st_v = is_ctx ? stored : 0u;
+    uint32_t st_v = stored & ctxm;
     const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
     const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
-    const bool is_trm = active && id == CABAC_REC_TRM;
-    const bool is_align = active && id == CABAC_REC_ALIGN;
     QuadDecInfo f;
-    f.c2 = is_ctx ? 8u : (is_trm ? 4u : 0u);
-    f.ep = (active && id == CABAC_REC_EP) ? 1u : 0u;
-    f.srmul = 1u << (22u - f.ep);
-    f.ctxm = is_ctx ? ~0u : 0u;
-    f.ntrm = is_trm ? 0u : ~0u;
-    f.alm = is_align ? ~0u : 0u;
-    f.key = is_ctx ? id : (0x200u + j);
-    const bool any_special = __ballot(is_align || is_trm) != 0;
+    f.c2 = (8u & ctxm) | (4u & trm_m);
+    f.ep = neg_mask((id ^ CABAC_REC_EP) - 1u) & 1u;
+    f.srmul = 0x400000u >> f.ep;  // 2^(22 - ep)
+    f.ctxm = ctxm;
+    f.ntrm = ~trm_m;
+    f.alm = aln_m;
+    f.key = sel(ctxm, id, 0x200u + j);
     next_rec = rec_safe[min(base + 16u + j, last_rec)];  // prefetch the next step's records
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
-    if (!any_special) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
+    if (special == 0) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
     else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
     const uint32_t my_bin = (bits >> j) & 1u;
-    if (is_ctx) rctx[id] = st_v;
-    if (active) out[base + j] = (uint8_t)my_bin;
+    rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
+    if (base + j < n) out[base + j] = (uint8_t)my_bin;
   }
 
   // bits shifted so far: everything moved into the window (8 * rp) minus value (16) minus look-ahead
