@@ -712,7 +712,9 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
   const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
   const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;          // getRenormBitsLPS; masked out when t == 0
-  const uint32_t nsh = (gc & nl) | (((rm >> 8) ^ 1u) & ngem);    // MPS path: rm < 512, so 1 iff rm < 256
+  uint32_t nm;  // MPS path: 1 iff rm < 256 (rm < 512): ngem & ~(rm >> 8) & 1 as ONE bit-op (hipcc splits off a v_not)
+  asm("v_bitop3_b32 %0, %1, %2, 1 bitop3:0x20" : "=v"(nm) : "v"(ngem), "v"(rm >> 8));
+  const uint32_t nsh = (gc & nl) | nm;
   uint32_t keep = ngem;
   if (kSpecial) keep |= ~row_bcast<I>(f.ntrm);                   // terminate bin 1 leaves value untouched (:184-185)
   w.hi = sel(keep, w.hi, e);
@@ -724,7 +726,8 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
     w.range |= 256u & ~(ngem | row_bcast<I>(f.ntrm));
   }
   {
-    const uint32_t tot = nsh + row_bcast<I>(f.ep);
+    uint32_t tot;  // nsh + the bypass bit, the broadcast folded into the add (hipcc keeps a separate v_mov_b32_dpp)
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(tot) : "v"(f.ep), "v"(nsh), "n"(I));
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
