@@ -25,7 +25,7 @@ EXPORTS = [
     "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
-    "cabac_hip_estimate_device", "cabac_hip_estimate_batch",
+    "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load_library():
     L.cabac_hip_count_emulations_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_estimate_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_estimate_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_estimate_from_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.cabac_synth_records.restype = None
@@ -183,6 +184,11 @@ class CabacHip:
         """BitEstimator_Std over a batch of bin strings: d_frac_bits[s] (uint64) = cost in 1/32768 bit."""
         self._check(self.L.cabac_hip_estimate_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_frac_bits),
                                                      vp(d_flags) if d_flags else None))
+
+    def estimate_from_device(self, n_sub, d_desc, d_records, d_state, d_rate, d_set, d_frac_bits, d_flags=0):
+        """estimate_device started from given context sets (format of ctx_init_device) instead of reset(qp, initId)."""
+        self._check(self.L.cabac_hip_estimate_from_device(self.h, n_sub, vp(d_desc), vp(d_records), vp(d_state), vp(d_rate),
+                                                          vp(d_set), vp(d_frac_bits), vp(d_flags) if d_flags else None))
 
     def estimate_batch(self, desc, records, check=False):
         """Host arrays through cabac_hip_estimate_batch: (frac_bits uint64[n], flags uint32[n])."""

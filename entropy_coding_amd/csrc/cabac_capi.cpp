@@ -234,6 +234,20 @@ int cabac_hip_estimate_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subs
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_estimate_from_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                   const uint16_t *d_records, const uint32_t *d_state, const uint8_t *d_rate,
+                                   const uint32_t *d_set, uint64_t *d_frac_bits, uint32_t *d_flags) {
+  if (!c || (n_sub && (!d_desc || !d_records || !d_frac_bits || !d_state || !d_rate || !d_set)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 4);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
+  HIP_TRY(c, cabac::launch_estimate(c->stream, n_sub, d_desc, d_records, d_frac_bits, d_flags, d_state, d_rate, d_set));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
+  return CABAC_HIP_OK;
+}
+
 int cabac_hip_ctx_init_device(cabac_hip_ctx *c, uint32_t n_sub, const int32_t *d_qp, const uint32_t *d_init_id,
                               uint32_t *d_state, uint8_t *d_rate) {
   if (!c || (n_sub && (!d_qp || !d_init_id || !d_state || !d_rate))) return fail(c, CABAC_HIP_ERR_INVALID, "null");

@@ -26,7 +26,8 @@ hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 
 // bit estimator (cabac_kernels_v4.hip)
 hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                           uint64_t *frac_bits, uint32_t *flags);
+                           uint64_t *frac_bits, uint32_t *flags, const uint32_t *start_state = nullptr,
+                           const uint8_t *start_rate = nullptr, const uint32_t *start_set = nullptr);
 
 // device binariser (cabac_binarize.hip)
 hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_offset, const uint32_t *se,

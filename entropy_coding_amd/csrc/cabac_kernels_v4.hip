@@ -911,7 +911,10 @@ __device__ __forceinline__ uint64_t row_sum64(uint64_t v) {  // sum over the 16 
 template <int W>
 __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                           const uint16_t *__restrict__ records,
-                                                          uint64_t *__restrict__ frac_bits, uint32_t *__restrict__ flags) {
+                                                          uint64_t *__restrict__ frac_bits, uint32_t *__restrict__ flags,
+                                                          const uint32_t *__restrict__ start_state,
+                                                          const uint8_t *__restrict__ start_rate,
+                                                          const uint32_t *__restrict__ start_set) {
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t frac[512];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
@@ -921,7 +924,17 @@ __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const 
   const uint32_t n = live ? d.n_records : 0u;
   const uint16_t *rec = records + d.rec_offset;
   uint32_t *rctx = ctx_all + (wave * kQuadSubs + row) * kQuadCtxStride;
-  quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+  if (start_state == nullptr) {
+    quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);  // reset(qp, initId), arith_codec.cpp:623-626
+  } else {
+    // contexts assigned from another coder's (contexts.hpp:254): set start_set[sub] of the given states, in the
+    // format of cabac_hip_ctx_init_device (m_state[0] | m_state[1] << 16, m_rate = 16 * rate0 + rate1)
+    const uint64_t set = live ? start_set[sub] : 0u;
+    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16) {
+      const uint32_t st = start_state[set * kNumCtx + k], rt = start_rate[set * kNumCtx + k];
+      rctx[k] = (st & kMask0) | (st & 0xffff0000u) | (((rt >> 4) - 2u) & 3u) | ((((rt & 15u) - 5u) & 7u) << 2);
+    }
+  }
   for (uint32_t k = threadIdx.x; k < 512u; k += 64u * W) frac[k] = c_frac_bits[k];
   __syncthreads();
 
@@ -968,14 +981,17 @@ __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const 
 }
 
 hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                           uint64_t *frac_bits, uint32_t *flags) {
+                           uint64_t *frac_bits, uint32_t *flags, const uint32_t *start_state, const uint8_t *start_rate,
+                           const uint32_t *start_set) {
   if (n_sub == 0) return hipSuccess;
   const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
   // four-wave workgroups pin one wave per SIMD (see decode_kernel_v4); small batches spread single waves
   if (waves >= 1024u)
-    hipLaunchKernelGGL(estimate_kernel<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, frac_bits, flags);
+    hipLaunchKernelGGL(estimate_kernel<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, frac_bits, flags,
+                       start_state, start_rate, start_set);
   else
-    hipLaunchKernelGGL(estimate_kernel<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, frac_bits, flags);
+    hipLaunchKernelGGL(estimate_kernel<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, frac_bits, flags, start_state,
+                       start_rate, start_set);
   return hipGetLastError();
 }
 

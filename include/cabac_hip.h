@@ -186,6 +186,16 @@ int cabac_hip_estimate_device(cabac_hip_ctx *ctx, uint32_t n_sub,
                               const cabac_substream_desc *d_desc, const uint16_t *d_records,
                               uint64_t *d_frac_bits, uint32_t *d_flags);
 
+/* The same from given contexts instead of reset(qp, init_id): replaces the assignment of another coder's
+ * contexts to the estimator (Ctx::operator=, contexts.hpp:254, as RDO does before costing candidates) followed
+ * by resetBits().  d_state / d_rate hold context sets in the format of cabac_hip_ctx_init_device
+ * (379 entries each: m_state[0] | m_state[1] << 16, m_rate); substream s starts from set d_set[s], so many
+ * candidate strings can share one start state.  qp / init_id of the descriptors are ignored.            */
+int cabac_hip_estimate_from_device(cabac_hip_ctx *ctx, uint32_t n_sub,
+                                   const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                                   const uint32_t *d_state, const uint8_t *d_rate, const uint32_t *d_set,
+                                   uint64_t *d_frac_bits, uint32_t *d_flags);
+
 /* Context-store initialisation only (Ctx::init, contexts.cpp:893-901, :915-920,
  * :996-1015): d_state[(s*379 + k)] = s0 | s1 << 16, d_rate[...] = m_rate for
  * substream s = (qp[s], init_id[s]).  Used by parity tests.                  */

@@ -877,6 +877,18 @@ int orc_estimate_records(const uint16_t *rec, long n, int qp, int init_id, uint6
   return estimate_record_run(&c, rec, n, frac_bits);
 }
 
+/* Started from given context states (the estimator's contexts assigned from another coder's, contexts.hpp:254,
+ * then resetBits()): s0 / s1 / rate as orc_ctx_init delivers them. */
+int orc_estimate_records_from(const uint16_t *rec, long n, const uint16_t *s0, const uint16_t *s1,
+                              const uint8_t *rate, uint64_t *frac_bits) {
+  ctx_store c;
+  memcpy(c.s0, s0, sizeof c.s0);
+  memcpy(c.s1, s1, sizeof c.s1);
+  memcpy(c.rate, rate, sizeof c.rate);
+  *frac_bits = 0;
+  return estimate_record_run(&c, rec, n, frac_bits);
+}
+
 /* ops: the binarisation helpers emit the same bins as for the encoder; encodeBinsEP / encodeRemAbsEP cost
  * 1 bit per bypass bin (arith_codec.cpp:640-677), which is what their expansion into EP records gives. */
 int orc_estimate_ops(const uint32_t *ops, long n_ops, int qp, int init_id, uint64_t *frac_bits) {

@@ -75,6 +75,9 @@ int orc_count_emulations(const uint8_t *bytes, long n);
  * the records before it. */
 int orc_estimate_records(const uint16_t *rec, long n, int qp, int init_id, uint64_t *frac_bits);
 int orc_estimate_ops(const uint32_t *ops, long n_ops, int qp, int init_id, uint64_t *frac_bits);
+/* the same from given context states (format of orc_ctx_init) instead of reset(qp, initId) */
+int orc_estimate_records_from(const uint16_t *rec, long n, const uint16_t *s0, const uint16_t *s1,
+                              const uint8_t *rate, uint64_t *frac_bits);
 void orc_estimate_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
                         uint64_t *frac_bits, uint32_t *flags);
 

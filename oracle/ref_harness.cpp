@@ -367,4 +367,42 @@ int ref_estimate_records(const uint16_t *rec, long n, int qp, int initId, uint64
   }
 }
 
+// Bit estimator started from the contexts another coder has reached (RDO: estimator.getCtx() = encoder.getCtx(),
+// contexts.hpp:254, then resetBits()).  `hist` is coded first (after reset(qp, initId)) to produce that state,
+// which is also dumped (s0, s1, rate) so that the oracle / the GPU can start from the same arrays.
+int ref_estimate_from_history(const uint16_t *hist, long n_hist, const uint16_t *rec, long n, int qp, int initId,
+                              uint64_t *frac_bits, uint16_t *s0, uint16_t *s1, uint8_t *rate) {
+  try {
+    auto run = [](BinEncIf &e, const uint16_t *r, long cnt) {
+      for (long i = 0; i < cnt; i++) {
+        unsigned id = r[i] & 0x1ff, bin = r[i] >> 15;
+        if (id < Ctx::NumberOfContexts) e.encodeBin(bin, id);
+        else if (id == 0x1fe) e.encodeBinEP(bin);
+        else if (id == 0x1ff) e.encodeBinTrm(bin);
+        else if (id == 0x1fd) e.align();
+        else if (id == 0x1fc) e.resetBits();
+        else if (id == 0x1fb) e.restart();
+      }
+    };
+    BitEstimator_Std a, b;
+    a.reset(qp, initId);
+    run(a, hist, n_hist);
+    b.reset(0, 0);
+    static_cast<BinEncIf &>(b).getCtx() = static_cast<BinEncIf &>(a).getCtx();
+    b.resetBits();
+    CtxStore<BinProbModel_Std> &st = static_cast<CtxStore<BinProbModel_Std> &>(static_cast<BinEncIf &>(b).getCtx());
+    for (unsigned k = 0; k < Ctx::NumberOfContexts; k++) {
+      s0[k] = st[k].getState0();
+      s1[k] = st[k].getState1();
+      rate[k] = st[k].getRate();
+    }
+    run(b, rec, n);
+    *frac_bits = b.getEstFracBits();
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
 } // extern "C"

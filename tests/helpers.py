@@ -71,6 +71,13 @@ class CodecLib:
         g("estimate_records").restype = ctypes.c_int
         g("estimate_records").argtypes = [u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u64p]
         if prefix == "orc_":
+            L.orc_estimate_records_from.restype = ctypes.c_int
+            L.orc_estimate_records_from.argtypes = [u16p, ctypes.c_long, u16p, u16p, u8p, u64p]
+        else:
+            L.ref_estimate_from_history.restype = ctypes.c_int
+            L.ref_estimate_from_history.argtypes = [u16p, ctypes.c_long, u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                                    u64p, u16p, u16p, u8p]
+        if prefix == "orc_":
             L.orc_estimate_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u16p, u64p, u32p]
             L.orc_ops_to_records.restype = ctypes.c_long
             L.orc_ops_to_records.argtypes = [u32p, ctypes.c_long, u16p, ctypes.c_long]
@@ -162,6 +169,26 @@ class CodecLib:
         out = ctypes.c_uint64(0)
         rc = getattr(self.lib, self.p + "estimate_records")(_ptr(rec, u16p), len(rec), qp, init_id, ctypes.byref(out))
         return rc, out.value
+
+    def estimate_records_from(self, rec, s0, s1, rate):
+        """oracle: cost of `rec` started from the given context states."""
+        rec = np.ascontiguousarray(rec, np.uint16)
+        out = ctypes.c_uint64(0)
+        rc = self.lib.orc_estimate_records_from(_ptr(rec, u16p), len(rec), _ptr(np.ascontiguousarray(s0, np.uint16), u16p),
+                                                _ptr(np.ascontiguousarray(s1, np.uint16), u16p),
+                                                _ptr(np.ascontiguousarray(rate, np.uint8), u8p), ctypes.byref(out))
+        return rc, out.value
+
+    def estimate_from_history(self, hist, rec, qp, init_id):
+        """reference: code `hist` after reset(qp, init_id), assign the contexts reached to a fresh estimator,
+        resetBits(), cost `rec`.  Returns (rc, bits, s0, s1, rate) — the states the estimator started from."""
+        hist = np.ascontiguousarray(hist, np.uint16)
+        rec = np.ascontiguousarray(rec, np.uint16)
+        s0, s1, rate = np.zeros(NUM_CTX, np.uint16), np.zeros(NUM_CTX, np.uint16), np.zeros(NUM_CTX, np.uint8)
+        out = ctypes.c_uint64(0)
+        rc = self.lib.ref_estimate_from_history(_ptr(hist, u16p), len(hist), _ptr(rec, u16p), len(rec), qp, init_id,
+                                                ctypes.byref(out), _ptr(s0, u16p), _ptr(s1, u16p), _ptr(rate, u8p))
+        return rc, out.value, s0, s1, rate
 
     def estimate_batch(self, desc, records):
         bits = np.zeros(len(desc), np.uint64)

@@ -68,3 +68,20 @@ def test_estimate_golden():
         assert rc == 0 and bits == int(g["est%d_bits" % k]), k
         rec = orc.ops_to_records(g["est%d_ops" % k])
         assert orc.estimate_records(rec, qp, iid) == (0, bits)
+
+
+@needs_ref
+def test_estimate_from_given_contexts_matches_reference():
+    """RDO use: the estimator's contexts assigned from a coder that has already adapted (Ctx::operator=), then
+    resetBits() and the candidate string.  The oracle starts from the dumped states."""
+    rng = np.random.default_rng(9300)
+    orc, ref = H.load_oracle(), H.load_ref()
+    for _ in range(10):
+        hist = H.random_records(rng, int(rng.integers(0, 5000)), ctx_frac=0.8, end_trm=False)
+        rec = H.random_records(rng, int(rng.integers(0, 600)), ctx_frac=0.7)
+        qp, iid = int(rng.integers(0, 64)), int(rng.integers(0, 3))
+        rc, bits, s0, s1, rate = ref.estimate_from_history(hist, rec, qp, iid)
+        assert rc == 0
+        assert orc.estimate_records_from(rec, s0, s1, rate) == (0, bits)
+        # the states are those the oracle's own update reaches
+        assert orc.estimate_records(np.concatenate([hist, np.array([0x1FC], np.uint16), rec]), qp, iid) == (0, bits)

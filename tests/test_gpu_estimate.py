@@ -92,3 +92,49 @@ def test_estimate_full_size_additivity(hip):
     d1, _ = H.make_desc([4096], [32], [2], H.SUB_FINISH)
     b, _ = hip.estimate_batch(d1, ep)
     assert int(b[0]) == 4096 << 15
+
+
+def test_estimate_from_given_contexts(hip):
+    """cabac_hip_estimate_from_device: many candidate strings sharing a few start states (contexts reached by coding
+    a history), against the oracle started from the same arrays."""
+    import torch
+    rng = np.random.default_rng(7900)
+    orc = H.load_oracle()
+    n_sets, n_cand = 5, 300
+    sets = []
+    for k in range(n_sets):  # a start state = the contexts after a history (oracle: reset + history, then dump via trace)
+        hist = H.random_records(rng, int(rng.integers(100, 4000)), ctx_frac=0.9, end_trm=False)
+        qp, iid = int(rng.integers(0, 64)), int(rng.integers(0, 3))
+        s0, s1, rate = orc.ctx_init(qp, iid)
+        s0, s1 = s0.astype(np.int64), s1.astype(np.int64)
+        for r in hist:  # update(), contexts.cpp:903-913
+            i, b = int(r) & 0x1FF, int(r) >> 15
+            if i < 379:
+                r0, r1 = int(rate[i]) >> 4, int(rate[i]) & 15
+                s0[i] -= (s0[i] >> r0) & 0x7FE0
+                s1[i] -= (s1[i] >> r1) & 0x7FFE
+                if b:
+                    s0[i] += (0x7FFF >> r0) & 0x7FE0
+                    s1[i] += (0x7FFF >> r1) & 0x7FFE
+        sets.append((s0.astype(np.uint16), s1.astype(np.uint16), rate))
+    recs = [H.random_records(rng, int(rng.integers(0, 300)), ctx_frac=0.75) for _ in range(n_cand)]
+    which = rng.integers(0, n_sets, size=n_cand).astype(np.uint32)
+    desc, _ = H.make_desc([len(r) for r in recs], [0] * n_cand, [0] * n_cand, H.SUB_FINISH)
+    records = np.concatenate(recs + [np.zeros(1, np.uint16)])
+    state = np.concatenate([(s[0].astype(np.uint32) | (s[1].astype(np.uint32) << 16)) for s in sets])
+    rate = np.concatenate([s[2] for s in sets]).astype(np.uint8)
+    dev = "cuda:0"
+    t = lambda a, dt: torch.from_numpy(a.view(dt).copy()).to(dev)
+    t_desc, t_rec = t(desc.view(np.uint8).reshape(-1), np.uint8), t(records, np.int16)
+    t_state, t_rate, t_set = t(state, np.int32), t(rate, np.uint8), t(which, np.int32)
+    t_bits = torch.zeros(n_cand, dtype=torch.int64, device=dev)
+    t_flags = torch.zeros(n_cand, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hip.estimate_from_device(n_cand, t_desc.data_ptr(), t_rec.data_ptr(), t_state.data_ptr(), t_rate.data_ptr(),
+                             t_set.data_ptr(), t_bits.data_ptr(), t_flags.data_ptr())
+    hip.synchronize()
+    got = t_bits.cpu().numpy().view(np.uint64)
+    assert not t_flags.cpu().numpy().any()
+    for i in range(n_cand):
+        s0, s1, rt = sets[int(which[i])]
+        assert orc.estimate_records_from(recs[i], s0, s1, rt) == (0, int(got[i])), i
