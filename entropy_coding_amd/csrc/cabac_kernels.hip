@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v1(uint32_t n_sub, const cab
       uint32_t last = src.src[src.pos - 1];
       ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
     }
-    if (!ok) flags |= CABAC_RES_BAD_STOP;
+    if (!ok && !src.underrun) flags |= CABAC_RES_BAD_STOP;  // an underrun throws before finish() is reached
   }
   const uint64_t any_bad = __ballot(bad != 0);
   if (lane == 0) {
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void decode_kernel_v2(uint32_t n_sub, uint32_t
       const uint32_t last = w.src[bytes_read - 1];
       ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
     }
-    if (!ok) flags |= CABAC_RES_BAD_STOP;
+    if (!ok && bytes_read <= w.cap) flags |= CABAC_RES_BAD_STOP;  // an underrun throws before finish() is reached
   }
   if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;  // the reference throws "FIFO exceeded" at that read
   if (bad) flags |= CABAC_RES_BAD_RECORD;
@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(64) void decode_kernel_v3(uint32_t n_sub, const cab
       const uint32_t last = src[bytes_read - 1];
       ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
     }
-    if (!ok) flags |= CABAC_RES_BAD_STOP;
+    if (!ok && bytes_read <= cap) flags |= CABAC_RES_BAD_STOP;  // an underrun throws before finish() is reached
   }
   if (bytes_read > cap) flags |= CABAC_RES_UNDERRUN;
   const uint64_t any_bad = __ballot(bad != 0);

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
       const uint32_t last = w.src[bytes_read - 1];
       ok = ((last << (8 + bits_needed)) & 0xffu) == 0x80u;
     }
-    if (!ok) flags |= CABAC_RES_BAD_STOP;
+    if (!ok && bytes_read <= w.cap) flags |= CABAC_RES_BAD_STOP;  // an underrun throws before finish() is reached
   }
   if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;
   const uint64_t bad_mask = __ballot(bad != 0);
