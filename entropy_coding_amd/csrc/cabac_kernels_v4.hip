@@ -830,10 +830,15 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
   const uint32_t last_rec = n != 0 ? n - 1u : 0u;
   uint32_t next_rec = rec_safe[min(j, last_rec)];
+  uint32_t prev_bin = 0, prev_idx = ~0u;  // the bins of the previous step, not yet stored
   for (uint32_t base = 0; base < max_n; base += 16) {
     // The fields of this step's record, as 0 / ~0 masks from arithmetic: a boolean expression would become a lane
     // mask in SGPRs, and every scalar instruction combining such masks waits ~55 cycles for the vector compare.
-    const uint32_t r = next_rec;  // loaded one step ago
+    uint32_t r = next_rec;  // loaded one step ago
+    asm volatile("" : "+v"(r));  // the wait for that load goes HERE ...
+    // ... and the bins of the previous step are stored only now: loads and stores share one in-order counter, so a
+    // store issued at the end of a step would still be in flight at this wait and add its whole latency to every step
+    if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
     const uint32_t actm = neg_mask(base + j - n);                        // ~0: a record of this substream
     const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);        // past the end: an id that is nothing
     const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
@@ -862,8 +867,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
     const uint32_t my_bin = (bits >> j) & 1u;
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
-    if (base + j < n) out[base + j] = (uint8_t)my_bin;
+    prev_bin = my_bin;
+    prev_idx = base + j;
   }
+  if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
 
   // bits shifted so far: everything moved into the window (8 * rp) minus value (16) minus look-ahead
   const uint32_t shifts = 8u * w.rp - 16u - (uint32_t)w.look;
