@@ -834,8 +834,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   for (uint32_t base = 0; base < max_n; base += 16) {
     // The fields of this step's record, as 0 / ~0 masks from arithmetic: a boolean expression would become a lane
     // mask in SGPRs, and every scalar instruction combining such masks waits ~55 cycles for the vector compare.
+    V5_TICK(t0);
     uint32_t r = next_rec;  // loaded one step ago
     asm volatile("" : "+v"(r));  // the wait for that load goes HERE ...
+    V5_TICK(t1);
     // ... and the bins of the previous step are stored only now: loads and stores share one in-order counter, so a
     // store issued at the end of a step would still be in flight at this wait and add its whole latency to every step
     if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
@@ -863,12 +865,21 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     f.key = sel(ctxm, id, 0x200u + j);
     next_rec = rec_safe[min(base + 16u + j, last_rec)];  // prefetch the next step's records
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
+    V5_TICK(t2);
     if (special == 0) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
     else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
+    V5_TICK(t3);
     const uint32_t my_bin = (bits >> j) & 1u;
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
+    V5_TICK(t4);
+    if (wave == 0) {
+      V5_ADD(8, t0, t1);   // waiting for the record
+      V5_ADD(9, t1, t2);   // prologue
+      V5_ADD(10, t2, t3);  // 16 chain steps incl. refills
+      V5_ADD(11, t3, t4);  // epilogue
+    }
   }
   if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
 

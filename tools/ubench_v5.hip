@@ -31,6 +31,27 @@ int main() {
     unsigned long long p[16];
     (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_v5_prof), sizeof(p));
     const double g = n_bins / 16.0;
+    {
+      // the decoder on the encoder's output: cycles per step of wave 0 of workgroup 0
+      uint8_t *d_bins; (void)hipMalloc(&d_bins, (size_t)n_sub * n_bins);
+      std::vector<cabac_substream_result> res(n_sub);
+      (void)hipMemcpy(res.data(), d_res, n_sub * sizeof(res[0]), hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL(decode_kernel_v4<4>, dim3(n_sub / 16), dim3(256), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_bins, d_res);
+      (void)hipDeviceSynchronize();
+      unsigned long long zero2[16] = {};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), zero2, sizeof(zero2));
+      hipEvent_t c, d; (void)hipEventCreate(&c); (void)hipEventCreate(&d);
+      (void)hipEventRecord(c);
+      hipLaunchKernelGGL(decode_kernel_v4<4>, dim3(n_sub / 16), dim3(256), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_bins, d_res);
+      (void)hipEventRecord(d); (void)hipDeviceSynchronize();
+      float dms; (void)hipEventElapsedTime(&dms, c, d);
+      unsigned long long q[16];
+      (void)hipMemcpyFromSymbol(q, HIP_SYMBOL(g_v5_prof), sizeof(q));
+      const double gg = n_bins / 16.0;
+      printf("decode %.3f ms; cycles per 16-bin step, wave 0: record wait %.0f prologue %.0f chain+refill %.0f epilogue %.0f\n", dms,
+             q[8] / gg, q[9] / gg, q[10] / gg, q[11] / gg);
+      (void)hipFree(d_bins);
+    }
     printf("kernel %.3f ms; cycles per 16-bin step, workgroup 0: context wave phase(a) %.0f barrier %.0f | chain wave chain %.0f barrier %.0f | output wave emit %.0f list %.0f\n",
            ms, p[2] / g, p[3] / g, p[4] / g, p[5] / g, p[0] / g, p[1] / g);
   }
