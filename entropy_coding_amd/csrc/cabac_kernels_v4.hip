@@ -656,15 +656,18 @@ __device__ __forceinline__ void quad_dec_refill(QuadDec &w) {
     w.pvalid = neg_mask(ahead - w.cap);                   // past the end of the substream the window is fed zeros
     w.pmask = 0;
   }
-  const uint32_t take = neg_mask((uint32_t)w.look - 32u);
-  const uint32_t half = (w.nxt >> ((w.rp & 2u) << 3)) & 0xffffu;
+  // look is 2..47 here, so "fewer than 32" is bit 5 clear; rp is even, so its bit 1 says which half of nxt holds
+  // the unit — and, when a unit is taken from the upper half, that the pointer crosses into the next dword
+  const uint32_t take = ~(uint32_t)((int32_t)(w.look << 26) >> 31);
+  const uint32_t upper = (uint32_t)((int32_t)(w.rp << 30) >> 31);
+  const uint32_t half = (w.nxt >> (upper & 16u)) & 0xffffu;
   const uint32_t unit = (((half & 0xffu) << 8) | (half >> 8)) & take;  // big-endian unit
   const uint64_t add = (uint64_t)unit << ((31 - w.look) & 63);
   w.hi |= (uint32_t)(add >> 32);
   w.lo |= (uint32_t)add;
   w.look += (int32_t)(16u & take);
   w.rp += 2u & take;
-  const uint32_t crossed = take & neg_mask((w.rp & 2u) - 1u);
+  const uint32_t crossed = take & upper;
   w.nxt = sel(crossed, w.nxt2, w.nxt);
   w.nxt2 = sel(crossed, w.nxt3, w.nxt2);
   w.pmask |= crossed;
