@@ -618,9 +618,12 @@ struct QuadDec {   // row-uniform values
   uint32_t hi, lo;   // 64-bit window: value in [62:47] (see v2)
   int32_t look;
   uint32_t range;
-  uint32_t rp, nxt, nxt2, nxt3;  // byte offset of the next unread 16-bit unit; the (little-endian) dword that holds
-                                 // it and the two after it
-  uint32_t pending, pvalid, pmask;  // the dword requested by the last check, whether it exists, who needs it
+  uint32_t rp;       // byte offset of the next unread 16-bit unit
+  uint32_t q_hi, q_lo;  // the two ring dwords from the one that holds that unit (big-endian: first unit on top),
+                     // fetched by the previous check
+  uint32_t *ring;    // this row's input ring in LDS: 64 byte-swapped dwords (+ dword 64 = a copy of dword 0)
+  uint32_t filled;   // bytes of the substream staged into the ring so far (a multiple of 64)
+  uint32_t pf_data, pf_off, pf_mask;  // a 64-byte block on its way: this lane's dword, its byte offset, wanted or not
   const uint8_t *src;
   uint32_t cap;
   const uint8_t *src_safe;  // src, or any readable address for an empty substream
@@ -641,37 +644,53 @@ struct QuadDecInfo {
   uint32_t key;   // ctxId of a context bin; a value unique in the row otherwise (so that it matches no other lane)
 };
 
+// Input.  The substream is staged into an LDS ring in 64-byte blocks — one dword per lane, byte-swapped so that
+// the first of its two 16-bit units is on top — by quad_dec_stage_load / _store below (every 4th step, a block
+// whenever fewer than 128 bytes are staged ahead; 4 steps consume at most 48).  A check takes its units from
+// (q_hi, q_lo), two ring dwords read by the PREVIOUS check, and reads the two dwords for the next one: no global
+// memory and no wait anywhere near the chain.
+//
 // Append one 16-bit unit to the window of every row that has fewer than 32 valid look-ahead bits: mask
 // arithmetic for all rows at once, no branch (the callers branch on scalar masks computed a step earlier).
-// Input buffer: the three dwords from the one that holds the next unit (nxt, nxt2, nxt3).  A check appends at
-// most two units, so it crosses at most one dword boundary; the dword that then becomes the third is requested
-// by the first pass of the check (one unconditional, aligned load from a clamped address) and only looked at
-// by the NEXT check — no wait for memory anywhere near the chain.
-template <bool kFirstPass>
-__device__ __forceinline__ void quad_dec_refill(QuadDec &w) {
-  if (kFirstPass) {
-    w.nxt3 = sel(w.pmask, w.pending & w.pvalid, w.nxt3);  // the dword requested by the previous check
-    const uint32_t ahead = (w.rp & ~3u) + 12u;
-    w.pending = *reinterpret_cast<const uint32_t *>(w.src_safe + min(ahead, w.last_dword));
-    w.pvalid = neg_mask(ahead - w.cap);                   // past the end of the substream the window is fed zeros
-    w.pmask = 0;
-  }
-  // look is 2..47 here, so "fewer than 32" is bit 5 clear; rp is even, so its bit 1 says which half of nxt holds
-  // the unit — and, when a unit is taken from the upper half, that the pointer crosses into the next dword
+template <bool kSecond>
+__device__ __forceinline__ void quad_dec_refill(QuadDec &w, uint32_t units) {  // units: the next two, first on top
+  // look is 2..47 here, so "fewer than 32" is bit 5 clear
   const uint32_t take = ~(uint32_t)((int32_t)(w.look << 26) >> 31);
-  const uint32_t upper = (uint32_t)((int32_t)(w.rp << 30) >> 31);
-  const uint32_t half = (w.nxt >> (upper & 16u)) & 0xffffu;
-  const uint32_t unit = (((half & 0xffu) << 8) | (half >> 8)) & take;  // big-endian unit
+  const uint32_t unit = (kSecond ? (units & 0xffffu) : (units >> 16)) & take;
   const uint64_t add = (uint64_t)unit << ((31 - w.look) & 63);
   w.hi |= (uint32_t)(add >> 32);
   w.lo |= (uint32_t)add;
   w.look += (int32_t)(16u & take);
   w.rp += 2u & take;
-  const uint32_t crossed = take & upper;
-  w.nxt = sel(crossed, w.nxt2, w.nxt);
-  w.nxt2 = sel(crossed, w.nxt3, w.nxt2);
-  w.pmask |= crossed;
 }
+
+// one check: up to two units per row, then the ring dwords for the next check
+__device__ __forceinline__ void quad_dec_check(QuadDec &w, bool second) {
+  const uint64_t q = (((uint64_t)w.q_hi << 32) | w.q_lo) << ((w.rp & 2u) << 3);  // rp odd unit: skip the first one
+  const uint32_t units = (uint32_t)(q >> 32);
+  quad_dec_refill<false>(w, units);
+  if (second) quad_dec_refill<true>(w, units);  // look >= 2 here, so two units always reach 32
+  const uint32_t at = (w.rp >> 2) & 63u;
+  w.q_hi = w.ring[at];
+  w.q_lo = w.ring[at + 1u];  // at == 63: dword 64 mirrors dword 0
+}
+
+// staging, part 1 (a step whose number is 0 mod 4): request the next 64-byte block if it is wanted
+__device__ __forceinline__ void quad_dec_stage_load(QuadDec &w, uint32_t j) {
+  w.pf_mask = neg_mask(w.filled - w.rp - 128u);  // fewer than 128 bytes ahead (filled >= rp always)
+  w.pf_off = w.filled + 4u * j;
+  w.pf_data = *reinterpret_cast<const uint32_t *>(w.src_safe + min(w.pf_off, w.last_dword));
+  w.filled += 64u & w.pf_mask;
+}
+// part 2 (the step after): into the ring; past the end of the substream the window is fed zeros
+__device__ __forceinline__ void quad_dec_stage_store(QuadDec &w) {
+  const uint32_t v = __builtin_bswap32(w.pf_data) & neg_mask(w.pf_off - w.cap);
+  const uint32_t at = (w.pf_off >> 2) & 63u;
+  w.ring[sel(w.pf_mask, at, 65u)] = v;                                  // dword 65: nobody reads it
+  w.ring[sel(w.pf_mask & neg_mask(at - 1u), 64u, 65u)] = v;             // at == 0: also the mirror
+}
+
+constexpr uint32_t kRingStride = 66;  // 64 ring dwords + the mirror of dword 0 + a dump word
 
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
 // every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip.  The cost
@@ -751,8 +770,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
   if ((I & 3) == 0 && refill != 0) {
-    quad_dec_refill<true>(w);
-    if (refill2 != 0) quad_dec_refill<false>(w);  // look >= 2 here, so two units always reach 32
+    quad_dec_check(w, refill2 != 0);
   }
 }
 
@@ -778,6 +796,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // five bits are then zero: state() is one SDWA add of the two halves, without masking
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint8_t rate_all[W * kQuadSubs * kQuadCtxStride];
+  __shared__ uint32_t ring_all[W * kQuadSubs * kRingStride];
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
@@ -813,13 +832,20 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     w.lo = first << 31;
   }
   w.look = 16;
+  // the first 192 bytes go into the ring at once (three blocks); the window itself started from bytes 0..3
+  w.ring = ring_all + (wave * kQuadSubs + row) * kRingStride;
+  for (uint32_t blk = 0; blk < 3; blk++) {
+    w.filled = 64u * blk;
+    w.rp = 0;  // "wanted"
+    quad_dec_stage_load(w, j);
+    w.pf_mask = ~0u;
+    quad_dec_stage_store(w);
+  }
+  w.filled = 192;
   w.rp = 4;
-  w.nxt = 4u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 4) : 0u;
-  w.nxt2 = 8u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 8) : 0u;
-  w.nxt3 = 12u < w.cap ? *reinterpret_cast<const uint32_t *>(w.src + 12) : 0u;
-  w.pending = 0;
-  w.pvalid = 0;
-  w.pmask = 0;
+  w.pf_mask = 0;
+  w.q_hi = w.ring[1];
+  w.q_lo = w.ring[2];
   w.range = 510;
   uint32_t bad = 0;
 
@@ -843,7 +869,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     V5_TICK(t1);
     // ... and the bins of the previous step are stored only now: loads and stores share one in-order counter, so a
     // store issued at the end of a step would still be in flight at this wait and add its whole latency to every step
+    // (the same wait covers the input block requested a step ago: into the ring with it before anything new is issued)
+    if ((base & 48u) == 16u) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
     if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
+    if ((base & 48u) == 0u) quad_dec_stage_load(w, j);    // steps 0, 4, 8, ...: request a block of input
     const uint32_t actm = neg_mask(base + j - n);                        // ~0: a record of this substream
     const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);        // past the end: an id that is nothing
     const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
