@@ -210,6 +210,55 @@ int cabac_hip_binarize_device(cabac_hip_ctx *ctx, uint32_t n_sub, const uint64_t
                               const uint32_t *d_se, const uint64_t *d_rec_offset,
                               uint32_t *d_n_records, uint16_t *d_records);
 
+/* ---- residual binariser on the device (encoder side) ----
+ * Transform-block coefficients -> the bin records CABACWriter::residual_coding (cabac_writer.cpp:2424-2525)
+ * asks its bin encoder for: ts_flag (:2527-2534), last_sig_coeff (:2639-2720) and, per coefficient group in
+ * reverse scan order, residual_coding_subblock (:2722-2872) with the context selection of CoeffCodingContext
+ * (context_modelling.hpp:71-244, context_modelling.cpp:7-106) and the scans of rom.cpp:148-260.
+ * Regular residual coding only: transform-skip blocks (residual_codingTS), SBT/MTS zero-out and the range
+ * extensions (extended Rice derivation, persistent Rice adaptation) are not covered.
+ * One block = one cabac_tu_desc; coefficients are int32 (the reference's TCoeff), raster, stride = width.
+ * For blocks wider/taller than 32 only the top-left 32x32 region is coded (rom.cpp:218-226). */
+typedef struct cabac_tu_desc {
+  uint64_t coeff_offset;      /* first coefficient of the block in d_coeff (in coefficients)       */
+  uint8_t log2_width;         /* 0..6                                                               */
+  uint8_t log2_height;        /* 0..6                                                               */
+  uint8_t channel;            /* 0 luma, 1 chroma (toChannelType(compID))                           */
+  uint8_t flags;              /* CABAC_TU_*                                                         */
+  uint8_t max_log2_tr_range;  /* SPS::getMaxLog2TrDynamicRange, 15 unless extended precision; 0 = 15 */
+  uint8_t reserved[3];
+} cabac_tu_desc;
+
+#define CABAC_TU_DEP_QUANT 0x1u   /* Slice::getDepQuantEnabledFlag                                   */
+#define CABAC_TU_SIGN_HIDING 0x2u /* Slice::getSignDataHidingEnabledFlag                             */
+#define CABAC_TU_TS_FLAG 0x4u     /* TU::isTSAllowed(tu, compID): transform_skip_flag = 0 is coded   */
+
+/* d_info[t] (may be NULL): scanPosLast in bits 15..0, what residual_coding records in its CUCtx argument */
+#define CABAC_TU_INFO_LAST_MASK 0xFFFFu
+#define CABAC_TU_INFO_MTS_VIOLATION 0x10000u /* a coded luma group with cgPosX > 3 or cgPosY > 3 (cabac_writer.cpp:2519-2522) */
+#define CABAC_TU_INFO_EMPTY 0x80000000u      /* all coefficients zero: the reference throws; no records     */
+#define CABAC_TU_INFO_BAD_DESC 0x40000000u   /* log2 size > 6 or channel > 1: no records                    */
+
+/* Context-set offsets used by residual coding (Ctx::*, contexts.cpp:77-770) */
+#define CABAC_CTX_SIG_COEFF_GROUP(ch) (86u + 2u * (ch))
+#define CABAC_CTX_SIG_FLAG(set) ((set) == 0 ? 90u : (set) == 1 ? 102u : (set) == 2 ? 110u : (set) == 3 ? 122u : (set) == 4 ? 130u : 142u)
+#define CABAC_CTX_PAR_FLAG(ch) ((ch) ? 171u : 150u)
+#define CABAC_CTX_GTX_FLAG(set) ((set) == 0 ? 182u : (set) == 1 ? 203u : (set) == 2 ? 214u : 235u)
+#define CABAC_CTX_LAST_X(ch) ((ch) ? 266u : 246u)
+#define CABAC_CTX_LAST_Y(ch) ((ch) ? 289u : 269u)
+#define CABAC_CTX_TRANSFORM_SKIP_FLAG(ch) (310u + (ch))
+
+/* Upper bound on the records of one block of n = min(32,w)*min(32,h) coded coefficients:
+ * 1 + 2*12 + 8 (ts flag, last position) + per coefficient 4 context bins, a 32-bin escape and a sign,
+ * + one group flag per 16.                                                                              */
+#define CABAC_TU_MAX_RECORDS(n) (33u + 38u * (n))
+
+/* Pass 1 (d_records == NULL): d_n_records[t] and d_info[t] only.  Pass 2: the records of block t are written
+ * at d_records + d_rec_offset[t] (the caller splices them into the substream's record buffer).          */
+int cabac_hip_residual_device(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_desc *d_tu, const int32_t *d_coeff,
+                              const uint64_t *d_rec_offset, uint32_t *d_n_records, uint32_t *d_info,
+                              uint16_t *d_records);
+
 /* ---- substream assembly on the device --------------
  * assemble: concatenate the coded substreams in descriptor order into d_payload — the effect of
  * OutputBitstream::addSubstream (bit_stream.cpp:139-150) on byte-aligned substreams (encode them with
@@ -245,7 +294,7 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
  * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize/estimate device call is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
  * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
- * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate) and ms[i] for the recorded calls in launch order,
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual) and ms[i] for the recorded calls in launch order,
  * returns their number and resets the ring.                                 */
 int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
 int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);

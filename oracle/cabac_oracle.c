@@ -447,6 +447,27 @@ static void rs_bins_ep(rec_sink *r, unsigned bins, unsigned n) {
   for (int i = (int)n - 1; i >= 0; i--) rs_put(r, CABAC_REC_EP, (bins >> i) & 1);
 }
 
+/* encodeRemAbsEP as bin records, arith_codec.cpp:426-458 */
+static void rs_rem_abs(rec_sink *r, unsigned v, unsigned rice, unsigned cutoff, int max_log2) {
+  if (v < (cutoff << rice)) {
+    unsigned length = (v >> rice) + 1;
+    rs_bins_ep(r, (1u << length) - 2, length);
+    rs_bins_ep(r, v & ((1u << rice) - 1), rice);
+  } else {
+    unsigned max_prefix = 32 - cutoff - (unsigned)max_log2, pl = 0, sl;
+    unsigned code = (v >> rice) - cutoff;
+    if (code >= ((1u << max_prefix) - 1)) {
+      pl = max_prefix;
+      sl = (unsigned)max_log2;
+    } else {
+      while (code > ((2u << pl) - 2u)) pl++;
+      sl = pl + rice + 1;
+    }
+    rs_bins_ep(r, (1u << (pl + cutoff)) - 1, pl + cutoff);
+    rs_bins_ep(r, ((code - ((1u << pl) - 1)) << rice) | (v & ((1u << rice) - 1)), sl);
+  }
+}
+
 long orc_ops_to_records(const uint32_t *ops, long n_ops, uint16_t *rec, long cap) {
   rec_sink r = {rec, cap, 0};
   for (long i = 0; i < n_ops; i++) {
@@ -455,28 +476,7 @@ long orc_ops_to_records(const uint32_t *ops, long n_ops, uint16_t *rec, long cap
     case ORC_OP_ENC_BIN: rs_put(&r, o[2], o[1]); break;
     case ORC_OP_ENC_EP: rs_put(&r, CABAC_REC_EP, o[1]); break;
     case ORC_OP_ENC_BINS_EP: rs_bins_ep(&r, o[1], o[2]); break;
-    case ORC_OP_ENC_REM_ABS: { /* arith_codec.cpp:426-458 */
-      unsigned v = o[1], rice = o[2], cutoff = o[3] & 0xff;
-      int max_log2 = (int)(o[3] >> 8);
-      if (v < (cutoff << rice)) {
-        unsigned length = (v >> rice) + 1;
-        rs_bins_ep(&r, (1u << length) - 2, length);
-        rs_bins_ep(&r, v & ((1u << rice) - 1), rice);
-      } else {
-        unsigned max_prefix = 32 - cutoff - (unsigned)max_log2, pl = 0, sl;
-        unsigned code = (v >> rice) - cutoff;
-        if (code >= ((1u << max_prefix) - 1)) {
-          pl = max_prefix;
-          sl = (unsigned)max_log2;
-        } else {
-          while (code > ((2u << pl) - 2u)) pl++;
-          sl = pl + rice + 1;
-        }
-        rs_bins_ep(&r, (1u << (pl + cutoff)) - 1, pl + cutoff);
-        rs_bins_ep(&r, ((code - ((1u << pl) - 1)) << rice) | (v & ((1u << rice) - 1)), sl);
-      }
-      break;
-    }
+    case ORC_OP_ENC_REM_ABS: rs_rem_abs(&r, o[1], o[2], o[3] & 0xff, (int)(o[3] >> 8)); break;
     case ORC_OP_ENC_TRM: rs_put(&r, CABAC_REC_TRM, o[1]); break;
     case ORC_OP_ALIGN: rs_put(&r, CABAC_REC_ALIGN, 0); break;
     case ORC_OP_UNARY_MAX: { /* cabac_writer.cpp:3072-3081 */
@@ -911,4 +911,246 @@ void orc_estimate_batch(const void *desc_, uint32_t first, uint32_t count, const
                                         &frac_bits[s]);
     flags[s] = rc == -2 ? CABAC_RES_BAD_RECORD : 0;
   }
+}
+
+/* ---------------------------------------------------------------- residual coding
+ * Restates CABACWriter::residual_coding (cabac_writer.cpp:2424-2525), ts_flag (:2527-2534), last_sig_coeff
+ * (:2639-2720), residual_coding_subblock (:2722-2872), CoeffCodingContext (context_modelling.hpp:71-244,
+ * context_modelling.cpp:7-106) and the grouped diagonal scan of rom.cpp:148-260, for regular residual coding
+ * without SBT/MTS zero-out and without the range extensions. */
+typedef struct {
+  int w, h, lw, lh;          /* block size                                              */
+  int cgw_l2, cgh_l2, cg_l2; /* coefficient-group size (g_log2SbbSize, rom.cpp:41-50)   */
+  int wg, hg;                /* groups per row / column after the 32x32 zero-out        */
+  int n_coded;               /* wg * hg << cg_l2                                        */
+} blk_geom;
+
+static void blk_geom_init(blk_geom *g, int lw, int lh) {
+  g->lw = lw; g->lh = lh; g->w = 1 << lw; g->h = 1 << lh;
+  if (lw == 0)      { g->cgw_l2 = 0; g->cgh_l2 = lh < 4 ? lh : 4; }
+  else if (lh == 0) { g->cgw_l2 = lw < 4 ? lw : 4; g->cgh_l2 = 0; }
+  else if (lw == 1) { g->cgw_l2 = 1; g->cgh_l2 = lh <= 2 ? 1 : 3; }
+  else if (lh == 1) { g->cgh_l2 = 1; g->cgw_l2 = lw <= 2 ? 1 : 3; }
+  else              { g->cgw_l2 = 2; g->cgh_l2 = 2; }
+  g->cg_l2 = g->cgw_l2 + g->cgh_l2;
+  g->wg = (g->w < 32 ? g->w : 32) >> g->cgw_l2;
+  g->hg = (g->h < 32 ? g->h : 32) >> g->cgh_l2;
+  g->n_coded = (g->wg * g->hg) << g->cg_l2;
+}
+
+/* up-right diagonal scan of a bw x bh rectangle: k-th position -> (x, y) (ScanGenerator, SCAN_DIAG, rom.cpp:72-92) */
+static void diag_positions(int bw, int bh, uint8_t *xs, uint8_t *ys) {
+  int k = 0;
+  for (int d = 0; d <= bw + bh - 2; d++) {
+    int y_hi = d < bh - 1 ? d : bh - 1, y_lo = d - (bw - 1) > 0 ? d - (bw - 1) : 0;
+    for (int y = y_hi; y >= y_lo; y--, k++) { xs[k] = (uint8_t)(d - y); ys[k] = (uint8_t)y; }
+  }
+}
+
+/* scan position -> (x, y); positions beyond the coded region of a zeroed-out block all map to the
+ * bottom-right sample (rom.cpp:218-226).  Returns the number of entries (w*h). */
+long orc_scan_order(int lw, int lh, uint32_t *out) {
+  blk_geom g;
+  if (lw < 0 || lw > 6 || lh < 0 || lh > 6) return -1;
+  blk_geom_init(&g, lw, lh);
+  uint8_t gx[64], gy[64], ix[16], iy[16];
+  diag_positions(g.wg, g.hg, gx, gy);
+  diag_positions(1 << g.cgw_l2, 1 << g.cgh_l2, ix, iy);
+  for (int p = 0; p < g.w * g.h; p++) {
+    if (p < g.n_coded) {
+      int cg = p >> g.cg_l2, i = p & ((1 << g.cg_l2) - 1);
+      out[p] = (uint32_t)((gx[cg] << g.cgw_l2) + ix[i]) | (uint32_t)((gy[cg] << g.cgh_l2) + iy[i]) << 16;
+    } else {
+      out[p] = (uint32_t)(g.w - 1) | (uint32_t)(g.h - 1) << 16;
+    }
+  }
+  return (long)g.w * g.h;
+}
+
+typedef struct {
+  int sum_abs;     /* plain sum of |neighbour| (templateAbsSum)                          */
+  int sum_clip;    /* sum of min(4 + (a & 1), a)          (sigCtxIdAbs)                  */
+  int n_nonzero;
+} tmpl_t;
+
+static tmpl_t tmpl_at(const int32_t *c, const blk_geom *g, int x, int y) {
+  static const int8_t dx[5] = {1, 2, 1, 0, 0}, dy[5] = {0, 0, 1, 1, 2};
+  tmpl_t t = {0, 0, 0};
+  for (int k = 0; k < 5; k++) {
+    int xx = x + dx[k], yy = y + dy[k];
+    if (xx >= g->w || yy >= g->h) continue;
+    int a = c[yy * g->w + xx];
+    if (a < 0) a = -a;
+    int lim = 4 + (a & 1);
+    t.sum_abs += a;
+    t.sum_clip += a < lim ? a : lim;
+    t.n_nonzero += a != 0;
+  }
+  return t;
+}
+
+static const uint8_t k_rice_of_sum[32] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2,
+                                          2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3}; /* g_goRiceParsCoeff */
+static unsigned rice_from(int sum_abs, int base_level) { /* deriveRice, context_modelling.hpp:262-266 */
+  int v = sum_abs - 5 * base_level;
+  return k_rice_of_sum[v < 0 ? 0 : v > 31 ? 31 : v];
+}
+static unsigned last_group_idx(unsigned p) { /* g_groupIdx, rom.cpp:21-25 */
+  return p < 4 ? p : 2 * floor_log2(p) + ((p >> (floor_log2(p) - 1)) & 1);
+}
+static unsigned last_min_in_group(unsigned gidx) { /* g_minInGroup, rom.cpp:18-19 */
+  return gidx < 4 ? gidx : (2u + (gidx & 1)) << ((gidx >> 1) - 1);
+}
+
+/* Returns the number of records (written up to cap), -1 for an all-zero block (the reference throws),
+ * -2 for a bad size.  info (may be NULL): scanPosLast | CABAC_TU_INFO_MTS_VIOLATION. */
+long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_log2_range, const int32_t *coeff,
+                          uint16_t *out, long cap, uint32_t *info) {
+  if (lw < 0 || lw > 6 || lh < 0 || lh > 6 || chroma < 0 || chroma > 1) return -2;
+  if (max_log2_range == 0) max_log2_range = 15;
+  blk_geom g;
+  blk_geom_init(&g, lw, lh);
+  rec_sink r = {out, cap, 0};
+  uint32_t *scan = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(g.w * g.h));
+  orc_scan_order(lw, lh, scan);
+#define SX(p) ((int)(scan[p] & 0xffff))
+#define SY(p) ((int)(scan[p] >> 16))
+#define COEF(p) (coeff[SY(p) * g.w + SX(p)])
+  const int cg_size = 1 << g.cg_l2;
+  const int n_cg = g.wg * g.hg;
+  uint8_t cg_sig[64]; /* by raster position in the group grid */
+  memset(cg_sig, 0, sizeof cg_sig);
+  int last = -1;
+  for (int p = 0; p < g.n_coded; p++)
+    if (COEF(p)) {
+      last = p;
+      int gx = SX(p) >> g.cgw_l2, gy = SY(p) >> g.cgh_l2;
+      cg_sig[gy * g.wg + gx] = 1;
+    }
+  if (last < 0) { free(scan); return -1; }
+  uint32_t info_bits = (uint32_t)last;
+
+  if (flags & CABAC_TU_TS_FLAG) rs_put(&r, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma), 0);
+
+  { /* last significant position, cabac_writer.cpp:2639-2720 */
+    const unsigned px = (unsigned)SX(last), py = (unsigned)SY(last);
+    static const uint8_t luma_off[7] = {0, 0, 0, 3, 6, 10, 15};
+    const unsigned off_x = chroma ? 0 : luma_off[lw], off_y = chroma ? 0 : luma_off[lh];
+    unsigned sh_x, sh_y;
+    if (chroma) {
+      sh_x = (unsigned)(g.w >> 3); if (sh_x > 2) sh_x = 2;
+      sh_y = (unsigned)(g.h >> 3); if (sh_y > 2) sh_y = 2;
+    } else {
+      sh_x = (unsigned)(lw + 1) >> 2; sh_y = (unsigned)(lh + 1) >> 2;
+    }
+    const unsigned gx = last_group_idx(px), gy = last_group_idx(py);
+    const unsigned max_x = last_group_idx((unsigned)(g.w < 32 ? g.w : 32) - 1), max_y = last_group_idx((unsigned)(g.h < 32 ? g.h : 32) - 1);
+    for (unsigned k = 0; k < gx; k++) rs_put(&r, CABAC_CTX_LAST_X(chroma) + off_x + (k >> sh_x), 1);
+    if (gx < max_x) rs_put(&r, CABAC_CTX_LAST_X(chroma) + off_x + (gx >> sh_x), 0);
+    for (unsigned k = 0; k < gy; k++) rs_put(&r, CABAC_CTX_LAST_Y(chroma) + off_y + (k >> sh_y), 1);
+    if (gy < max_y) rs_put(&r, CABAC_CTX_LAST_Y(chroma) + off_y + (gy >> sh_y), 0);
+    if (gx > 3) rs_bins_ep(&r, px - last_min_in_group(gx), (gx - 2) >> 1);
+    if (gy > 3) rs_bins_ep(&r, py - last_min_in_group(gy), (gy - 2) >> 1);
+  }
+
+  const unsigned trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u; /* cabac_writer.cpp:2482 */
+  int state = 0;
+  int budget = (((g.w < 32 ? g.w : 32) * (g.h < 32 ? g.h : 32)) * 28) >> 4; /* :2485-2489 */
+  const int last_cg = last >> g.cg_l2;
+  (void)n_cg;
+
+  for (int cg = last_cg; cg >= 0; cg--) {
+    const int lo = cg << g.cg_l2, hi = lo + cg_size - 1;
+    const int cgx = SX(lo) >> g.cgw_l2, cgy = SY(lo) >> g.cgh_l2;
+    const int coded_group = cg_sig[cgy * g.wg + cgx];
+    if (cg != last_cg && cg != 0) {
+      const int right = cgx + 1 < g.wg ? cg_sig[cgy * g.wg + cgx + 1] : 0;
+      const int below = cgy + 1 < g.hg ? cg_sig[(cgy + 1) * g.wg + cgx] : 0;
+      rs_put(&r, CABAC_CTX_SIG_COEFF_GROUP(chroma) + (unsigned)(right | below), (unsigned)coded_group);
+      if (!coded_group) continue;
+    }
+    if (!chroma && coded_group && (cgx > 3 || cgy > 3)) info_bits |= CABAC_TU_INFO_MTS_VIOLATION;
+
+    const int first = cg == last_cg ? last : hi;
+    const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
+    int n_nz = 0, first_nz = first, last_nz = -1;
+    unsigned signs = 0;
+    int p = first;
+    /* pass 1: context-coded flags while the budget lasts */
+    for (; p >= lo && budget >= 4; p--) {
+      const int v = COEF(p);
+      const int x = SX(p), y = SY(p), diag = x + y;
+      const tmpl_t t = tmpl_at(coeff, &g, x, y);
+      if (n_nz || p != infer) {
+        int ofs = (t.sum_clip + 1) >> 1;
+        if (ofs > 3) ofs = 3;
+        if (diag < 2) ofs += 4;
+        if (!chroma && diag < 5) ofs += 4;
+        const int set = (state > 1 ? state - 1 : 0) * 2 + chroma;
+        rs_put(&r, CABAC_CTX_SIG_FLAG(set) + (unsigned)ofs, v != 0);
+        budget--;
+      }
+      if (v) {
+        int ofs = 0;
+        if (p != last) { /* ctxOffsetAbs: the template of this position (context_modelling.hpp:131-143) */
+          int s1 = t.sum_clip - t.n_nonzero;
+          ofs = (s1 < 4 ? s1 : 4) + 1;
+          if (diag == 0) ofs += chroma ? 5 : 15;
+          else if (!chroma) ofs += diag < 3 ? 10 : diag < 10 ? 5 : 0;
+        }
+        int rem = (v < 0 ? -v : v) - 1;
+        if (p != last) signs <<= 1;
+        if (v < 0) signs++;
+        n_nz++;
+        first_nz = p;
+        if (p > last_nz) last_nz = p;
+        rs_put(&r, CABAC_CTX_GTX_FLAG(2 + chroma) + (unsigned)ofs, rem != 0);
+        budget--;
+        if (rem) {
+          rem--;
+          rs_put(&r, CABAC_CTX_PAR_FLAG(chroma) + (unsigned)ofs, (unsigned)(rem & 1));
+          rs_put(&r, CABAC_CTX_GTX_FLAG(chroma) + (unsigned)ofs, (rem >> 1) != 0);
+          budget -= 2;
+        }
+      }
+      state = (int)((trans >> ((state << 2) + ((v & 1) << 1))) & 3);
+    }
+    const int bypass_from = p; /* positions bypass_from .. lo are coded without contexts */
+    /* pass 2: remainders of the context-coded positions */
+    for (int q = first; q > bypass_from; q--) {
+      const int v = COEF(q), a = v < 0 ? -v : v;
+      if (a >= 4) {
+        const tmpl_t t = tmpl_at(coeff, &g, SX(q), SY(q));
+        rs_rem_abs(&r, (unsigned)(a - 4) >> 1, rice_from(t.sum_abs, 4), 5, max_log2_range);
+      }
+    }
+    /* pass 3: whole levels in bypass mode */
+    for (int q = bypass_from; q >= lo; q--) {
+      const int v = COEF(q), a = v < 0 ? -v : v;
+      const tmpl_t t = tmpl_at(coeff, &g, SX(q), SY(q));
+      const unsigned rice = rice_from(t.sum_abs, 0);
+      const int pos0 = (state < 2 ? 1 : 2) << rice;
+      const unsigned rem = a == 0 ? (unsigned)pos0 : a <= pos0 ? (unsigned)(a - 1) : (unsigned)a;
+      rs_rem_abs(&r, rem, rice, 5, max_log2_range);
+      state = (int)((trans >> ((state << 2) + ((a & 1) << 1))) & 3);
+      if (a) {
+        n_nz++;
+        first_nz = q;
+        if (q > last_nz) last_nz = q;
+        signs = (signs << 1) + (v < 0);
+      }
+    }
+    unsigned n_signs = (unsigned)n_nz;
+    if ((flags & CABAC_TU_SIGN_HIDING) && last_nz - first_nz >= 4) { /* hideSign, SBH_THRESHOLD = 4 */
+      n_signs--;
+      signs >>= 1;
+    }
+    rs_bins_ep(&r, signs, n_signs);
+  }
+#undef SX
+#undef SY
+#undef COEF
+  free(scan);
+  if (info) *info = info_bits;
+  return r.n;
 }

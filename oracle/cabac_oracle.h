@@ -81,6 +81,13 @@ int orc_estimate_records_from(const uint16_t *rec, long n, const uint16_t *s0, c
 void orc_estimate_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
                         uint64_t *frac_bits, uint32_t *flags);
 
+/* Residual coding (CABACWriter::residual_coding, cabac_writer.cpp:2424-2872): a coefficient block -> bin records.
+ * flags = CABAC_TU_* of include/cabac_hip.h.  Returns the number of records (out filled up to cap), -1 for an
+ * all-zero block (the reference throws), -2 for a bad size.  orc_scan_order: scan position -> x | y << 16. */
+long orc_residual_records(int log2_width, int log2_height, int chroma, unsigned flags, int max_log2_range,
+                          const int32_t *coeff, uint16_t *out, long cap, uint32_t *info);
+long orc_scan_order(int log2_width, int log2_height, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,5 +126,37 @@ def main():
     print("wrote", os.path.join(GOLD, "vectors.npz"), os.path.getsize(os.path.join(GOLD, "vectors.npz")), "bytes")
 
 
+def residual(ref):
+    """(f) residual coding: coefficient blocks -> the bin records the reference's CABACWriter::residual_coding
+    emits (ref_residual_records in oracle/ref_harness.cpp).  tests/golden/residual.npz"""
+    rng = np.random.default_rng(0xF2F2)
+    sizes = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
+    meta, coeffs, recs = [], [], []
+    for i, (w, h) in enumerate(sizes * 3):
+        k = i // len(sizes)
+        c = H.random_block(rng, w, h, density=[0.15, 0.5, 1.0][k], big=[0.02, 0.1, 0.4][k],
+                           huge=0.03 if k == 2 else 0.0, last_frac=[0.4, 1.0, 1.0][k])
+        chroma = int(rng.integers(0, 2))
+        flags = int(rng.integers(0, 8))
+        if max(w, h) > 32:
+            flags &= ~H.TU_TS_FLAG
+        r, _ = ref.residual_records(c, chroma, flags)
+        meta.append((int(np.log2(w)), int(np.log2(h)), chroma, flags))
+        coeffs.append(c.ravel())
+        recs.append(r)
+    out = {"n_blocks": np.array([len(meta)], np.int32), "meta": np.array(meta, np.int32),
+           "coeff": np.concatenate(coeffs).astype(np.int32),
+           "coeff_off": np.concatenate([[0], np.cumsum([len(c) for c in coeffs])]).astype(np.int64),
+           "records": np.concatenate(recs).astype(np.uint16),
+           "rec_off": np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.int64)}
+    path = os.path.join(GOLD, "residual.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "residual":
+        residual(H.load_ref())
+    else:
+        main()
+        residual(H.load_ref())

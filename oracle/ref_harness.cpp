@@ -405,4 +405,96 @@ int ref_estimate_from_history(const uint16_t *hist, long n_hist, const uint16_t 
   }
 }
 
+
+// ---- residual coding ---------------------------------------------------
+// The reference's own CABACWriter::residual_coding (cabac_writer.cpp:2424-2525, with last_sig_coeff
+// :2639-2720 and residual_coding_subblock :2722-2872) run on a TransformUnit built here around a
+// caller-supplied coefficient block; the bins it asks the encoder for are captured as bin records.
+} // extern "C"
+namespace {
+struct RecordingEncoder : public BinEncoder_Std {  // encodeRemAbsEP stays the reference's (it calls encodeBinsEP)
+  std::vector<uint16_t> rec;
+  void encodeBin(unsigned bin, unsigned ctxId) override { rec.push_back(uint16_t((bin & 1u) << 15 | ctxId)); }
+  void encodeBinEP(unsigned bin) override { rec.push_back(uint16_t((bin & 1u) << 15 | 0x1fe)); }
+  void encodeBinsEP(unsigned bins, unsigned numBins) override {
+    for (int i = int(numBins) - 1; i >= 0; i--) rec.push_back(uint16_t(((bins >> i) & 1u) << 15 | 0x1fe));
+  }
+  void encodeBinTrm(unsigned bin) override { rec.push_back(uint16_t((bin & 1u) << 15 | 0x1ff)); }
+};
+
+template <class T> T *zeroed() { return reinterpret_cast<T *>(calloc(1, sizeof(T))); }  // never destroyed
+
+struct ResidualRig {
+  SPS *sps = zeroed<SPS>();
+  Slice *slice = zeroed<Slice>();
+  CodingStructure *cs = zeroed<CodingStructure>();
+  CodingUnit *cu = zeroed<CodingUnit>();
+  ResidualRig() {
+    static bool rom = false;
+    if (!rom) { initROM(); rom = true; }
+    sps->m_bitDepths.recon[0] = sps->m_bitDepths.recon[1] = 10;
+    sps->m_log2MaxTbSize = 6;
+    slice->m_pcSPS = sps;
+    cs->sps = std::shared_ptr<const SPS>(sps, [](const SPS *) {});
+    cs->slice = std::shared_ptr<Slice>(slice, [](Slice *) {});
+    cu->cs = cs;
+    cu->slice = slice;
+  }
+};
+}  // namespace
+extern "C" {
+
+// flags: bit0 dep_quant, bit1 sign_data_hiding, bit2 transform-skip enabled in the SPS (max TS size 32),
+//        bit3 the cuCtx pointer is passed (info[1..4] = violatesLfnstConstrained[luma|chroma<<1], lfnstLastScanPos,
+//        violatesMtsCoeffConstraint, mtsLastScanPos).  comp: 0 Y, 1 Cb, 2 Cr.
+long ref_residual_records(int width, int height, int comp, int flags, const int32_t *coeff, uint16_t *out, long cap,
+                          int32_t *info) {
+  try {
+    static ResidualRig rig;
+    rig.slice->m_depQuantEnabledFlag = flags & 1;
+    rig.slice->m_signDataHidingEnabledFlag = (flags >> 1) & 1;
+    rig.sps->m_transformSkipEnabledFlag = (flags >> 2) & 1;
+    rig.sps->m_log2MaxTransformSkipBlockSize = 5;
+    TransformUnit tu;
+    tu.initData();
+    tu.chromaFormat = CHROMA_420;
+    const ComponentID cid = ComponentID(comp);
+    for (int c = 0; c < 3; c++)
+      tu.blocks.push_back(CompArea(ComponentID(c), CHROMA_420, 0, 0, c == comp ? width : 0, c == comp ? height : 0));
+    tu.cu = rig.cu;
+    tu.cs = rig.cs;
+    tu.chType = toChannelType(cid);
+    std::vector<TCoeff> buf(coeff, coeff + (size_t)width * height);
+    for (auto &p : tu.m_coeffs) p = nullptr;
+    tu.m_coeffs[comp] = buf.data();
+    tu.cbf[comp] = 1;
+    RecordingEncoder enc;
+    CABACWriter w(enc);
+    CUCtx cuCtx(0);
+    w.residual_coding(tu, cid, (flags & 8) ? &cuCtx : nullptr);
+    if (info) {
+      info[0] = (int32_t)enc.rec.size();
+      info[1] = int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_LUMA]) | int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_CHROMA]) << 1;
+      info[2] = cuCtx.lfnstLastScanPos;
+      info[3] = cuCtx.violatesMtsCoeffConstraint;
+      info[4] = cuCtx.mtsLastScanPos;
+    }
+    if ((long)enc.rec.size() > cap) { strcpy(g_err, "capacity"); return -3; }
+    if (!enc.rec.empty()) memcpy(out, enc.rec.data(), enc.rec.size() * sizeof(uint16_t));
+    return (long)enc.rec.size();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// The scan the reference's ROM holds for a block (rom.cpp:148-260): out[scanPos] = x | y << 16.
+long ref_scan_order(int width, int height, uint32_t *out) {
+  static ResidualRig rig;
+  const ScanElement *scan = g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG][gp_sizeIdxInfo->idxFrom(width)][gp_sizeIdxInfo->idxFrom(height)];
+  if (!scan) return -1;
+  for (long i = 0; i < (long)width * height; i++) out[i] = scan[i].x | uint32_t(scan[i].y) << 16;
+  return (long)width * height;
+}
+
 } // extern "C"

@@ -37,6 +37,16 @@ DESC_DTYPE = np.dtype(
 )
 RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
 
+# cabac_tu_desc and friends (include/cabac_hip.h)
+TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_height", "u1"), ("channel", "u1"),
+                     ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
+TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG = 1, 2, 4
+TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
+
+
+def TU_MAX_RECORDS(n):
+    return 33 + 38 * n
+
 
 def _ptr(a, ty):
     return a.ctypes.data_as(ty)
@@ -197,6 +207,52 @@ class CodecLib:
                                     bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _ptr(flags, u32p))
         return bits, flags
 
+    # -- residual coding ---------------------------------------
+    def residual_records(self, coeff, chroma=0, flags=0, max_log2_range=15, with_cuctx=True):
+        """coeff: (h, w) int32 block -> (records, scanPosLast, mts_violation).  Raises ValueError on an all-zero block."""
+        coeff = np.ascontiguousarray(coeff, dtype=np.int32)
+        h, w = coeff.shape
+        cap = TU_MAX_RECORDS(min(w, 32) * min(h, 32))
+        out = np.zeros(cap, np.uint16)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        if self.p == "orc_":
+            f = self.lib.orc_residual_records
+            f.restype = ctypes.c_long
+            f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, i32p, u16p,
+                          ctypes.c_long, u32p]
+            info = ctypes.c_uint32(0)
+            n = f(int(np.log2(w)), int(np.log2(h)), chroma, flags, max_log2_range, _ptr(coeff, i32p), _ptr(out, u16p),
+                  cap, ctypes.byref(info))
+            if n == -1:
+                raise ValueError("empty block")
+            assert 0 <= n <= cap, n
+            return out[:n].copy(), info.value & 0xFFFF, bool(info.value & TU_INFO_MTS_VIOLATION)
+        f = self.lib.ref_residual_records
+        f.restype = ctypes.c_long
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, u16p, ctypes.c_long, i32p]
+        info = np.zeros(8, np.int32)
+        assert max_log2_range == 15
+        n = f(w, h, 1 if chroma else 0, (flags & 7) | (8 if with_cuctx else 0), _ptr(coeff, i32p), _ptr(out, u16p), cap,
+              _ptr(info, i32p))
+        if n == -1:
+            self.lib.ref_last_error.restype = ctypes.c_char_p
+            raise ValueError(self.lib.ref_last_error().decode(errors="replace"))
+        assert 0 <= n <= cap, n
+        return out[:n].copy(), info
+
+    def scan_order(self, w, h):
+        out = np.zeros(w * h, np.uint32)
+        if self.p == "orc_":
+            f = self.lib.orc_scan_order
+            args = (int(np.log2(w)), int(np.log2(h)))
+        else:
+            f = self.lib.ref_scan_order
+            args = (w, h)
+        f.restype = ctypes.c_long
+        f.argtypes = [ctypes.c_int, ctypes.c_int, u32p]
+        assert f(*args, _ptr(out, u32p)) == w * h
+        return out
+
     def encode_batch(self, desc, records, bytes_total):
         out = np.zeros(max(bytes_total, 1), np.uint8)
         res = np.zeros(len(desc), RESULT_DTYPE)
@@ -349,3 +405,25 @@ def make_desc(lengths, qps, init_ids, flags=SUB_FINISH, capacities=None):
     d["qp"] = qps
     d["init_id"] = np.asarray(init_ids, np.uint32) | flags
     return d, int(capacities.sum())
+
+
+def random_block(rng, w, h, density=0.3, big=0.05, huge=0.0, last_frac=1.0):
+    """A (h, w) int32 coefficient block as a quantiser leaves it: mostly small levels with density falling off
+    away from DC, some large ones, zero outside the top-left 32x32 (rom.cpp:218-226) and beyond a random
+    'last' diagonal; never all-zero."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    fall = np.exp(-(xx + yy) / max(2.0, (w + h) * 0.35))
+    nz = rng.random((h, w)) < density * (0.25 + fall)
+    mag = 1 + rng.geometric(0.55, (h, w)) - 1
+    bigm = rng.random((h, w)) < big
+    mag = np.where(bigm, mag + rng.integers(2, 40, (h, w)), mag)
+    if huge:
+        mag = np.where(rng.random((h, w)) < huge, rng.integers(1000, 32768, (h, w)), mag)
+    sign = np.where(rng.random((h, w)) < 0.5, -1, 1)
+    c = (nz * mag * sign).astype(np.int32)
+    c[(xx + yy) > last_frac * (min(w, 32) + min(h, 32))] = 0
+    c[:, 32:] = 0
+    c[32:, :] = 0
+    if not c.any():
+        c[rng.integers(0, min(h, 32)), rng.integers(0, min(w, 32))] = int(rng.integers(1, 4)) * int(rng.choice([-1, 1]))
+    return c

@@ -1,0 +1,85 @@
+"""CPU: the residual-coding restatement (oracle/cabac_oracle.c, orc_residual_records) pinned to the reference's own
+CABACWriter::residual_coding (cabac_writer.cpp:2424-2872) compiled from its sources (oracle/_ref, build container
+only), and everywhere else to the golden vectors that compiled reference produced (tests/golden/residual.npz,
+oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+SIZES = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
+needs_ref = pytest.mark.skipif(not H.ref_available(), reason="compiled reference only exists in the build container")
+
+
+@needs_ref
+def test_scan_order_matches_reference_rom():
+    orc, ref = H.load_oracle(), H.load_ref()
+    for w, h in SIZES:
+        assert np.array_equal(orc.scan_order(w, h), ref.scan_order(w, h)), (w, h)
+
+
+def _check(orc, ref, c, chroma, flags):
+    want, info = ref.residual_records(c, chroma, flags)   # flags bit2 there: transform skip enabled in the SPS, max size 32
+    if max(c.shape) > 32:
+        flags &= ~H.TU_TS_FLAG                             # TU::isTSAllowed (unit_tools.cpp:651-664) is the caller's to evaluate
+    got, last, mts = orc.residual_records(c, chroma, flags)
+    assert np.array_equal(got, want), (c.shape, chroma, flags)
+    # what residual_coding leaves in its CUCtx (cabac_writer.cpp:2461-2477, :2519-2522), from scanPosLast
+    h, w = c.shape
+    if w >= 4 and h >= 4:
+        thr = 7 if (w, h) in ((4, 4), (8, 8)) else 15
+        assert bool(info[1] >> chroma & 1) == (last > thr)
+        assert bool(info[2]) == (last >= 1)
+    if not chroma:
+        assert bool(info[4]) == (last >= 1) and bool(info[3]) == mts
+
+
+@needs_ref
+@pytest.mark.parametrize("chroma", [0, 1])
+def test_random_blocks_match_reference(chroma):
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0xF2 + chroma)
+    for w, h in SIZES:
+        for k in range(12):
+            c = H.random_block(rng, w, h, density=[0.05, 0.3, 0.7, 1.0][k % 4], big=[0.0, 0.05, 0.3][k % 3],
+                               huge=0.02 if k % 5 == 4 else 0.0, last_frac=[1.0, 0.5, 0.2][k % 3])
+            _check(orc, ref, c, chroma, k % 8)
+
+
+@needs_ref
+def test_edge_blocks_match_reference():
+    orc, ref = H.load_oracle(), H.load_ref()
+    for w, h in [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (2, 8), (8, 2), (16, 1), (1, 16), (4, 32), (64, 4)]:
+        we, he = min(w, 32), min(h, 32)
+        cases = []
+        z = np.zeros((h, w), np.int32)
+        for (y, x) in [(0, 0), (he - 1, we - 1), (0, we - 1), (he - 1, 0)]:  # a single coefficient at each corner
+            for v in (1, -1, 2, -3, 4, 5, 32767, -32768):
+                c = z.copy(); c[y, x] = v; cases.append(c)
+        c = z.copy(); c[:he, :we] = 1; cases.append(c)                 # dense ones
+        c = z.copy(); c[:he, :we] = -32768; cases.append(c)            # every level an escape: the context-bin budget runs out
+        c = z.copy(); c[:he, :we] = 3; c[0, 0] = -7; cases.append(c)
+        c = z.copy(); c[:he, :we] = np.where((np.add.outer(np.arange(he), np.arange(we)) & 1) == 0, 2, -1); cases.append(c)
+        for c in cases:
+            for flags in (0, 1, 2, 3, 7):
+                for chroma in (0, 1):
+                    _check(orc, ref, c, chroma, flags)
+    with pytest.raises(ValueError):
+        orc.residual_records(np.zeros((8, 8), np.int32))
+    with pytest.raises(ValueError):
+        ref.residual_records(np.zeros((8, 8), np.int32))
+
+
+def test_golden_blocks():
+    orc = H.load_oracle()
+    g = np.load(os.path.join(H.GOLDEN, "residual.npz"))
+    n = int(g["n_blocks"][0])
+    assert n >= 100
+    for k in range(n):
+        lw, lh, chroma, flags = [int(x) for x in g["meta"][k]]
+        c = g["coeff"][g["coeff_off"][k]: g["coeff_off"][k + 1]].reshape(1 << lh, 1 << lw)
+        want = g["records"][g["rec_off"][k]: g["rec_off"][k + 1]]
+        got, last, mts = orc.residual_records(c, chroma, flags)
+        assert np.array_equal(got, want), k
