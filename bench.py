@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--no-residual", action="store_true", help="skip the residual-binariser leg (C4, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
@@ -95,6 +96,57 @@ def cpu_baseline(cfg, desc, records, budget_s):
         "encode_mbins_s": round(bins_done / t_enc / 1e6, 2),
         "decode_mbins_s": round(bins_done / t_dec / 1e6, 2),
     }
+
+
+
+def residual_leg(hip, n_tiles, unique=256, reps=4):
+    """Coefficient blocks -> bin records (cabac_hip_residual_device), both passes, on n_tiles tiles of
+    workload.RESIDUAL_TILE_MIX (`unique` generated tiles, replicated on the device).  Checked against the md5 the
+    compiled reference produced for the first blocks (tests/golden/residual_bench.json) and replica against replica."""
+    import torch
+    from entropy_coding_amd import workload as W
+    unique = min(unique, n_tiles)
+    copies = max(n_tiles // unique, 1)
+    tus, coeff, tile_first = W.build_residual_tiles(unique)
+    n_u, c_u = len(tus), len(coeff)
+    all_tus = np.tile(tus, copies)
+    all_tus["coeff_offset"] += np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(c_u), n_u)
+    n = len(all_tus)
+    t_tu = torch.from_numpy(all_tus.view(np.uint8).reshape(-1).copy()).cuda()
+    t_co = torch.from_numpy(coeff).cuda().repeat(copies)
+    t_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    t_info = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.profile_enable(2 * reps + 2)
+    for _ in range(reps + 1):
+        hip.residual_device(n, t_tu.data_ptr(), t_co.data_ptr(), 0, t_cnt.data_ptr(), t_info.data_ptr(), 0)
+    hip.synchronize()
+    cnt = t_cnt.to(torch.int64)
+    t_off = torch.cumsum(cnt, 0) - cnt
+    n_bins = int(cnt.sum().item())
+    t_rec = torch.zeros(n_bins, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(reps + 1):
+        hip.residual_device(n, t_tu.data_ptr(), t_co.data_ptr(), t_off.data_ptr(), t_cnt.data_ptr(), t_info.data_ptr(),
+                            t_rec.data_ptr())
+    prof = [ms for k, ms in hip.profile_read() if k == 5]
+    p1, p2 = float(np.mean(prof[1:reps + 1])), float(np.mean(prof[reps + 2:]))
+    per = n_bins // copies
+    ok = n_bins == per * copies and all(bool(torch.equal(t_rec[:per], t_rec[r * per:(r + 1) * per])) for r in range(1, copies))
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "residual_bench.json")))
+    k = gold["n_blocks"]
+    first = t_rec[: int(cnt[:k].sum().item())].cpu().numpy().view(np.uint16)
+    ok = ok and hashlib.md5(first.tobytes()).hexdigest() == gold["records_md5"] and not bool((t_info < 0).any().item())
+    n_coef = c_u * copies
+    bytes1 = 4 * n_coef + (16 + 4 + 4) * n
+    bytes2 = 4 * n_coef + 2 * n_bins + (16 + 8 + 4 + 4) * n
+    return {"kernel": "residual_kernel", "workload": "%d tiles x %d transform blocks (1080p/64 tile mix), %d unique tiles" % (n_tiles, n_u // unique, unique),
+            "blocks": n, "coefficients": n_coef, "bins": n_bins,
+            "kernel_ms": {"pass1_count": round(p1, 4), "pass2_write": round(p2, 4)},
+            "mcoeff_s": round(n_coef / ((p1 + p2) * 1e-3) / 1e6, 1), "mbins_s": round(n_bins / ((p1 + p2) * 1e-3) / 1e6, 1),
+            "algorithmic_bytes_per_launch": {"pass1_count": bytes1, "pass2_write": bytes2},
+            "achieved_gbps": {"pass1_count": round(bytes1 / (p1 * 1e-3) / 1e9, 2), "pass2_write": round(bytes2 / (p2 * 1e-3) / 1e9, 2)},
+            "frac_of_hbm_peak": round(bytes2 / (p2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "records_match_reference": bool(ok)}
 
 
 def main():
@@ -209,6 +261,11 @@ def main():
     est_ok = not bool(t_est_flags.any().item())
     est_bits_per_bin = float(t_est.sum().item()) / 32768.0 / max(n_bins, 1)
 
+    # ---- residual binariser on coefficient blocks, outside the timed region ----------
+    residual = None
+    if world == 1 and cfg.name == "C4" and not args.no_residual:
+        residual = residual_leg(hip, n_sub)
+
     # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
     gather_ms = None
     if world > 1:
@@ -285,12 +342,16 @@ def main():
             "achieved_gbps": round((2 * n_bins + 48 * n_sub) / (est_ms * 1e-3) / 1e9, 3),
             "estimated_bits_per_bin": round(est_bits_per_bin, 5),
             "coded_bits_per_bin": round(8.0 * out_bytes / max(n_bins, 1), 5), "flags_clear": est_ok}
+        if residual is not None:
+            line["residual"] = residual
         if gather_ms is not None:
             line["sizes_allgather_ms"] = round(gather_ms, 3)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, desc, records, args.cpu_seconds)
         if not line["hash_match"]:
             line["error"] = "bitstream hash / round-trip mismatch"
+        elif residual is not None and not residual["records_match_reference"]:
+            line["error"] = "residual records differ from the reference's"
         print(json.dumps(line))
     hip.close()
     if world > 1:

@@ -17,12 +17,18 @@ DESC_DTYPE = np.dtype([("rec_offset", "<u8"), ("byte_offset", "<u8"), ("n_record
                        ("byte_capacity", "<u4"), ("qp", "<i4"), ("init_id", "<u4")])
 RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
 assert DESC_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 8
+# cabac_tu_desc (include/cabac_hip.h): one transform block for the residual binariser
+TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_height", "u1"), ("channel", "u1"),
+                     ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
+assert TU_DTYPE.itemsize == 16
+TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG = 1, 2, 4
+TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
 
 EXPORTS = [
     "cabac_hip_encode_bound", "cabac_hip_init", "cabac_hip_destroy", "cabac_hip_strerror",
     "cabac_hip_last_error", "cabac_hip_set_stream", "cabac_hip_synchronize", "cabac_hip_set_variant",
     "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
-    "cabac_hip_binarize_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
+    "cabac_hip_binarize_device", "cabac_hip_residual_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
@@ -62,6 +68,7 @@ def load_library():
     L.cabac_hip_decode_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_ctx_init_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_binarize_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    L.cabac_hip_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
@@ -204,6 +211,11 @@ class CabacHip:
     def binarize_device(self, n_sub, d_se_offset, d_se, d_rec_offset, d_n_records, d_records):
         self._check(self.L.cabac_hip_binarize_device(self.h, n_sub, vp(d_se_offset), vp(d_se), vp(d_rec_offset),
                                                      vp(d_n_records), vp(d_records)))
+
+    def residual_device(self, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records):
+        """cabac_hip_residual_device: coefficient blocks -> bin records (pass 1 when d_records == 0)."""
+        self._check(self.L.cabac_hip_residual_device(self.h, n_tu, vp(d_tu), vp(d_coeff), vp(d_rec_offset),
+                                                     vp(d_n_records), vp(d_info), vp(d_records)))
 
     def assemble_device(self, n_sub, d_desc, d_results, d_bytes, d_payload, payload_capacity, d_offsets):
         self._check(self.L.cabac_hip_assemble_device(self.h, n_sub, vp(d_desc), vp(d_results), vp(d_bytes), vp(d_payload),

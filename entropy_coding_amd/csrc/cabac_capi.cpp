@@ -438,4 +438,18 @@ int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t n_sub, const uint64_t *
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_residual_device(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_desc *d_tu, const int32_t *d_coeff,
+                              const uint64_t *d_rec_offset, uint32_t *d_n_records, uint32_t *d_info,
+                              uint16_t *d_records) {
+  if (!c || (n_tu && (!d_tu || !d_coeff || !d_n_records || (d_records && !d_rec_offset))))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 5);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
+  HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
+  return CABAC_HIP_OK;
+}
+
 }  // extern "C"

@@ -33,6 +33,10 @@ hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream
 hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_offset, const uint32_t *se,
                            const uint64_t *rec_offset, uint32_t *n_records, uint16_t *records);
 
+// residual binariser (cabac_residual.hip)
+hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                           const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records);
+
 // substream assembly (cabac_assemble.hip)
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,

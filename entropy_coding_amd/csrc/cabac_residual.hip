@@ -1,0 +1,397 @@
+// Residual binariser (encoder side): transform-block coefficients -> bin records.
+// Restates for the device
+//   CABACWriter::residual_coding            entropy_codec/cabac_writer.cpp:2424-2525
+//   CABACWriter::ts_flag                    cabac_writer.cpp:2527-2534   (flag value 0 only)
+//   CABACWriter::last_sig_coeff             cabac_writer.cpp:2639-2720
+//   CABACWriter::residual_coding_subblock   cabac_writer.cpp:2722-2872
+//   CoeffCodingContext                      common/context_modelling.hpp:71-244, context_modelling.cpp:7-106
+//   grouped diagonal scan, g_log2SbbSize    common/rom.cpp:41-50, :72-92, :148-260
+//   BinEncIf::encodeRemAbsEP                entropy_codec/arith_codec.cpp:426-458
+//
+// The reference walks a block serially; almost nothing in that walk is serial by nature.  Context choice reads
+// a five-coefficient template of the INPUT (not of coded state), so every position knows its contexts on its
+// own.  What couples positions is (a) the budget of context-coded bins, which only ever decreases — position p
+// is context coded iff budget - (bins of the positions before it) >= 4, a prefix sum; (b) the dependent-
+// quantisation state, a 4-state machine driven by coefficient parity; (c) where each position's bins land in
+// the output, another prefix sum.  Layout: one block per 16-lane DPP row (four blocks per wave), lane = scan
+// position inside the coefficient group, one loop iteration per coefficient group in coding order; row-wide
+// sums come from ballots + popcounts, the output offsets from a 4-step DPP suffix scan.  The budget, the state
+// and the write offset are carried from group to group as row-uniform values.
+// Reads 4 B per coefficient (plus template re-reads that hit L1/L2), writes 2 B per bin: HBM-bound by
+// construction; no LDS, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cabac_hip.h"
+#include "cabac_kernels.h"
+
+namespace cabac {
+
+namespace {
+
+// k-th position of the up-right diagonal scan of a bw x bh rectangle, packed x | y << 4.
+struct DiagLut {
+  uint8_t grid[4][4][64];   // [log2 groups per row][log2 groups per column][group index]
+  uint8_t in_cg[5][5][16];  // [log2 group width][log2 group height][position in group]
+};
+
+constexpr void fill_diag(uint8_t *out, int bw, int bh) {
+  int k = 0;
+  for (int d = 0; d <= bw + bh - 2; d++) {
+    const int y_hi = d < bh - 1 ? d : bh - 1;
+    const int y_lo = d - (bw - 1) > 0 ? d - (bw - 1) : 0;
+    for (int y = y_hi; y >= y_lo; y--, k++) out[k] = (uint8_t)((d - y) | (y << 4));
+  }
+}
+
+constexpr DiagLut make_lut() {
+  DiagLut t{};
+  for (int a = 0; a < 4; a++)
+    for (int b = 0; b < 4; b++) fill_diag(t.grid[a][b], 1 << a, 1 << b);
+  for (int a = 0; a < 5; a++)
+    for (int b = 0; b + a < 5; b++) fill_diag(t.in_cg[a][b], 1 << a, 1 << b);
+  return t;
+}
+
+__constant__ DiagLut c_diag = make_lut();
+
+// g_goRiceParsCoeff (rom.cpp:27-29) as thresholds: 0 below 7, 1 below 14, 2 below 28, else 3
+__device__ __forceinline__ uint32_t rice_of(int sum_abs, int base_level) {
+  int v = sum_abs - 5 * base_level;
+  v = v < 0 ? 0 : v;
+  return (uint32_t)(v >= 7) + (uint32_t)(v >= 14) + (uint32_t)(v >= 28);
+}
+
+__device__ __forceinline__ uint32_t group_idx(uint32_t p) {  // g_groupIdx, rom.cpp:21-25
+  const uint32_t fl = 31u - (uint32_t)__builtin_clz(p | 1u);
+  return p < 4u ? p : 2u * fl + ((p >> (fl - 1u)) & 1u);
+}
+__device__ __forceinline__ uint32_t min_in_group(uint32_t g) {  // g_minInGroup, rom.cpp:18-19
+  return g < 4u ? g : (2u + (g & 1u)) << ((g >> 1) - 1u);
+}
+
+template <int N>
+__device__ __forceinline__ uint32_t row_shl(uint32_t v) {  // lane l <- lane l + N of the same row, 0 outside
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 | N, 0xf, 0xf, true);
+}
+
+// sum of v over the lanes above this one in its row (the positions coded before it)
+__device__ __forceinline__ uint32_t row_sum_above(uint32_t v) {
+  uint32_t s = v;
+  s += row_shl<1>(s);
+  s += row_shl<2>(s);
+  s += row_shl<4>(s);
+  s += row_shl<8>(s);
+  return s - v;
+}
+
+__device__ __forceinline__ uint32_t row_bits(bool pred, uint32_t row_shift) {  // this row's 16 ballot bits
+  return (uint32_t)(__ballot(pred) >> row_shift) & 0xffffu;
+}
+
+struct EpCode {  // two bypass code words, MSB first
+  uint32_t code1, len1, code2, len2;
+};
+
+// encodeRemAbsEP with cutoff 5 (COEF_REMAIN_BIN_REDUCTION), arith_codec.cpp:426-458
+__device__ __forceinline__ EpCode rem_abs_code(uint32_t value, uint32_t rice, uint32_t max_log2) {
+  EpCode s;
+  const uint32_t cutoff = 5u;
+  if (value < (cutoff << rice)) {
+    s.len1 = (value >> rice) + 1u;
+    s.code1 = (1u << s.len1) - 2u;
+    s.code2 = value & ((1u << rice) - 1u);
+    s.len2 = rice;
+  } else {
+    const uint32_t max_prefix = 32u - cutoff - max_log2;
+    const uint32_t code = (value >> rice) - cutoff;
+    uint32_t prefix_len, suffix_len;
+    if (code >= ((1u << max_prefix) - 1u)) {
+      prefix_len = max_prefix;
+      suffix_len = max_log2;
+    } else {
+      prefix_len = 31u - (uint32_t)__builtin_clz(code + 1u);  // smallest n with code <= 2^(n+1) - 2
+      suffix_len = prefix_len + rice + 1u;
+    }
+    s.len1 = prefix_len + cutoff;
+    s.code1 = (1u << s.len1) - 1u;
+    s.code2 = ((code - ((1u << prefix_len) - 1u)) << rice) | (value & ((1u << rice) - 1u));
+    s.len2 = suffix_len;
+  }
+  return s;
+}
+
+constexpr uint32_t kRowsPerBlock = 16;  // 256 threads
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
+                                                        const int32_t *__restrict__ coeff_all,
+                                                        const uint64_t *__restrict__ rec_offset,
+                                                        uint32_t *__restrict__ n_records,
+                                                        uint32_t *__restrict__ info_out,
+                                                        uint16_t *__restrict__ records) {
+  const uint32_t lane = threadIdx.x & 63u, l = lane & 15u, row_shift = lane & 48u;
+  const uint32_t tu_idx = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 4);
+  bool live = tu_idx < n_tu;
+
+  // ---- geometry (row-uniform) -------------------------------------------------------------------
+  uint32_t lw = 0, lh = 0, chroma = 0, flags = 0, max_log2 = 15;
+  const int32_t *coeff = coeff_all;
+  if (live) {
+    const cabac_tu_desc d = tus[tu_idx];
+    lw = d.log2_width;
+    lh = d.log2_height;
+    chroma = d.channel;
+    flags = d.flags;
+    max_log2 = d.max_log2_tr_range ? d.max_log2_tr_range : 15u;
+    coeff = coeff_all + d.coeff_offset;
+  }
+  const bool bad = live && (lw > 6u || lh > 6u || chroma > 1u || max_log2 > 20u);
+  if (bad) lw = lh = chroma = 0;
+  live = live && !bad;
+  const uint32_t w = 1u << lw, h = 1u << lh;
+  uint32_t cgw_l2, cgh_l2;  // g_log2SbbSize, rom.cpp:41-50
+  if (lw == 0u) { cgw_l2 = 0u; cgh_l2 = lh < 4u ? lh : 4u; }
+  else if (lh == 0u) { cgw_l2 = lw < 4u ? lw : 4u; cgh_l2 = 0u; }
+  else if (lw == 1u) { cgw_l2 = 1u; cgh_l2 = lh <= 2u ? 1u : 3u; }
+  else if (lh == 1u) { cgh_l2 = 1u; cgw_l2 = lw <= 2u ? 1u : 3u; }
+  else { cgw_l2 = 2u; cgh_l2 = 2u; }
+  const uint32_t cg_l2 = cgw_l2 + cgh_l2, cg_size = 1u << cg_l2;
+  const uint32_t we = w < 32u ? w : 32u, he = h < 32u ? h : 32u;
+  const uint32_t lwg = (31u - (uint32_t)__builtin_clz(we)) - cgw_l2, lhg = (31u - (uint32_t)__builtin_clz(he)) - cgh_l2;
+  const uint32_t wg = 1u << lwg, hg = 1u << lhg, n_cg = live ? wg * hg : 0u;
+  const uint32_t in_cg = c_diag.in_cg[cgw_l2][cgh_l2][l & (cg_size - 1u)];
+  const uint32_t ix = in_cg & 15u, iy = in_cg >> 4;
+  const uint8_t *grid = c_diag.grid[lwg][lhg];
+  const bool lane_in_cg = l < cg_size;
+
+  // ---- sweep 1: last significant position and the per-group significance map ---------------------
+  uint32_t max_cg = n_cg;
+  max_cg = max(max_cg, (uint32_t)__shfl_xor((int)max_cg, 16));
+  max_cg = max(max_cg, (uint32_t)__shfl_xor((int)max_cg, 32));
+  max_cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_cg);
+  uint64_t sig_map = 0;  // bit gy * wg + gx
+  int last = -1;
+  for (uint32_t cg = 0; cg < max_cg; cg++) {
+    const bool on = cg < n_cg && lane_in_cg;
+    int32_t c = 0;
+    uint32_t gpos = 0;
+    if (cg < n_cg) gpos = grid[cg];
+    const uint32_t gx = gpos & 15u, gy = gpos >> 4;
+    if (on) c = coeff[(((gy << cgh_l2) + iy) << lw) + (gx << cgw_l2) + ix];
+    const uint32_t nz = row_bits(c != 0, row_shift);
+    if (nz) {
+      last = (int)((cg << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
+      sig_map |= 1ull << (gy * wg + gx);
+    }
+  }
+  const bool empty = live && last < 0;
+  live = live && !empty;
+
+  uint16_t *out = (records && live) ? records + rec_offset[tu_idx] : nullptr;
+  uint32_t off = 0;  // records produced so far (row-uniform)
+  uint32_t info = live ? (uint32_t)last : (bad ? CABAC_TU_INFO_BAD_DESC : empty ? CABAC_TU_INFO_EMPTY : 0u);
+
+  // ---- ts_flag and the last position ------------------------------------------------------------------
+  if (live) {
+    if (flags & CABAC_TU_TS_FLAG) {
+      if (out && l == 0u) out[0] = (uint16_t)CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma);
+      off = 1;
+    }
+    const uint32_t lcg = (uint32_t)last >> cg_l2;
+    const uint32_t lgp = grid[lcg];
+    const uint32_t lin = c_diag.in_cg[cgw_l2][cgh_l2][(uint32_t)last & (cg_size - 1u)];
+    const uint32_t px = ((lgp & 15u) << cgw_l2) + (lin & 15u), py = ((lgp >> 4) << cgh_l2) + (lin >> 4);
+    const uint32_t luma_off_x = lw < 3u ? 0u : lw == 3u ? 3u : lw == 4u ? 6u : lw == 5u ? 10u : 15u;
+    const uint32_t luma_off_y = lh < 3u ? 0u : lh == 3u ? 3u : lh == 4u ? 6u : lh == 5u ? 10u : 15u;
+    const uint32_t off_x = chroma ? 0u : luma_off_x, off_y = chroma ? 0u : luma_off_y;
+    const uint32_t sh_x = chroma ? min(w >> 3, 2u) : (lw + 1u) >> 2, sh_y = chroma ? min(h >> 3, 2u) : (lh + 1u) >> 2;
+    const uint32_t gix = group_idx(px), giy = group_idx(py);
+    const uint32_t nx = gix + (gix < group_idx(we - 1u) ? 1u : 0u), ny = giy + (giy < group_idx(he - 1u) ? 1u : 0u);
+    const uint32_t sx = gix > 3u ? (gix - 2u) >> 1 : 0u, sy = giy > 3u ? (giy - 2u) >> 1 : 0u;
+    if (out) {
+      if (l < nx) out[off + l] = (uint16_t)((l < gix ? CABAC_REC_BIN : 0u) | (CABAC_CTX_LAST_X(chroma) + off_x + (l >> sh_x)));
+      if (l < ny) out[off + nx + l] = (uint16_t)((l < giy ? CABAC_REC_BIN : 0u) | (CABAC_CTX_LAST_Y(chroma) + off_y + (l >> sh_y)));
+      if (l < sx) out[off + nx + ny + l] = (uint16_t)(((((px - min_in_group(gix)) >> (sx - 1u - l)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+      if (l < sy) out[off + nx + ny + sx + l] = (uint16_t)(((((py - min_in_group(giy)) >> (sy - 1u - l)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+    }
+    off += nx + ny + sx + sy;
+  }
+
+  // ---- sweep 2: the coefficient groups in coding order ----------------------------------------------
+  const uint32_t trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u;  // cabac_writer.cpp:2482
+  const bool any_dq = __ballot(live && trans != 0u) != 0ull;
+  int budget = (int)((we * he * 28u) >> 4);  // cabac_writer.cpp:2485-2489
+  uint32_t state = 0;
+  const int last_cg = live ? (last >> cg_l2) : -1;
+  int top_cg = last_cg;
+  top_cg = max(top_cg, __shfl_xor(top_cg, 16));
+  top_cg = max(top_cg, __shfl_xor(top_cg, 32));
+  top_cg = __builtin_amdgcn_readfirstlane(top_cg);
+  const uint32_t sig_set_base = chroma;  // SigFlag[chType + 2 * max(0, state - 1)]
+
+  for (int cg = top_cg; cg >= 0; cg--) {
+    const bool row_on = cg <= last_cg;  // this row still has groups to code
+    const uint32_t gpos = row_on ? grid[cg] : 0u;
+    const uint32_t gx = gpos & 15u, gy = gpos >> 4;
+    const uint32_t gbit = gy * wg + gx;
+    const bool coded_group = (sig_map >> gbit) & 1ull;
+    const bool has_flag = row_on && cg != last_cg && cg != 0;
+    if (has_flag) {
+      const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
+      const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
+      if (out && l == 0u)
+        out[off] = (uint16_t)((coded_group ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)));
+      off += 1u;
+    }
+    const bool walk = row_on && (coded_group || cg == 0 || cg == last_cg);  // residual_coding_subblock goes past its early return
+    if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
+
+    const int lo = cg << cg_l2;
+    const int first = cg == last_cg ? last : lo + (int)cg_size - 1;
+    const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
+    const int pos = lo + (int)l;
+    const bool act = walk && lane_in_cg && pos <= first;
+    const uint32_t x = (gx << cgw_l2) + ix, y = (gy << cgh_l2) + iy, diag = x + y;
+
+    // coefficient and its template (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176)
+    int32_t c = 0;
+    int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
+    if (act) {
+      const int32_t *p = coeff + (y << lw) + x;
+      c = p[0];
+      auto add = [&](int32_t v) {
+        const int a = v < 0 ? -v : v;
+        sum_abs += a;
+        sum_clip += min(a, 4 + (a & 1));
+        n_tmpl += a != 0;
+      };
+      if (x + 1u < w) {
+        add(p[1]);
+        if (x + 2u < w) add(p[2]);
+        if (y + 1u < h) add(p[w + 1u]);
+      }
+      if (y + 1u < h) {
+        add(p[w]);
+        if (y + 2u < h) add(p[2u * w]);
+      }
+    }
+    const uint32_t a = (uint32_t)(c < 0 ? -c : c);
+    const bool nzero = c != 0;
+
+    // which bins exist, and how far the context-bin budget reaches
+    const uint32_t m_nz = row_bits(nzero, row_shift);
+    const uint32_t above_mask = ~0u << (l + 1u);  // positions coded before this one
+    const bool sig_coded = act && !(pos == infer && (m_nz & above_mask) == 0u);
+    const uint32_t m_sig = row_bits(sig_coded, row_shift);
+    const uint32_t m_gt1 = row_bits(a > 1u, row_shift);
+    const uint32_t spent_before = (uint32_t)__builtin_popcount(m_sig & above_mask) + (uint32_t)__builtin_popcount(m_nz & above_mask) +
+                                  2u * (uint32_t)__builtin_popcount(m_gt1 & above_mask);
+    const bool ctx_mode = act && (budget - (int)spent_before >= 4);
+    const uint32_t m_ctx = row_bits(ctx_mode, row_shift);
+    const uint32_t n_ctx_bins = (uint32_t)__builtin_popcount(m_sig & m_ctx) + (uint32_t)__builtin_popcount(m_nz & m_ctx) +
+                                2u * (uint32_t)__builtin_popcount(m_gt1 & m_ctx);
+
+    // dependent-quantisation state on entry to each position (cabac_writer.cpp:2787, :2837)
+    uint32_t my_state = 0;
+    if (any_dq) {
+      const uint32_t m_act = row_bits(act, row_shift);
+      const uint32_t m_par = row_bits(act && (a & 1u), row_shift);
+      uint32_t st = state;
+#pragma unroll
+      for (int i = 15; i >= 0; i--) {
+        my_state = (int)l == i ? st : my_state;
+        const uint32_t nxt = (trans >> ((st << 2) + (((m_par >> i) & 1u) << 1))) & 3u;
+        st = ((m_act >> i) & 1u) ? nxt : st;
+      }
+      state = st;
+    }
+
+    // pass 1 records of this position
+    uint32_t rec_sig = 0, rec_g1 = 0, rec_par = 0, rec_g2 = 0, n1 = 0;
+    if (ctx_mode) {
+      uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + (diag < 2u ? 4u : 0u);
+      if (chroma == 0u) ofs += diag < 5u ? 4u : 0u;
+      const uint32_t set = sig_set_base + 2u * (my_state > 1u ? my_state - 1u : 0u);
+      rec_sig = (nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_FLAG(set) + ofs);
+      uint32_t aofs = 0;
+      if (pos != last) {  // ctxOffsetAbs, context_modelling.hpp:131-143
+        aofs = (uint32_t)min(sum_clip - n_tmpl, 4) + 1u;
+        if (diag == 0u) aofs += chroma ? 5u : 15u;
+        else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
+      }
+      const uint32_t rem = a - 2u;  // only read when a > 1
+      rec_g1 = (a > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(2u + chroma) + aofs);
+      rec_par = ((rem & 1u) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_PAR_FLAG(chroma) + aofs);
+      rec_g2 = ((rem >> 1) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(chroma) + aofs);
+      n1 = (sig_coded ? 1u : 0u) + (nzero ? (a > 1u ? 3u : 1u) : 0u);
+    }
+
+    // pass 2 (remainder of a context-coded level) or pass 3 (whole level in bypass mode)
+    EpCode ep = {0, 0, 0, 0};
+    if (ctx_mode) {
+      if (a >= 4u) ep = rem_abs_code((a - 4u) >> 1, rice_of(sum_abs, 4), max_log2);
+    } else if (act) {
+      const uint32_t rice = rice_of(sum_abs, 0);
+      const uint32_t pos0 = (my_state < 2u ? 1u : 2u) << rice;
+      const uint32_t rem = a == 0u ? pos0 : (a <= pos0 ? a - 1u : a);
+      ep = rem_abs_code(rem, rice, max_log2);
+    }
+    const uint32_t n23 = ep.len1 + ep.len2;
+    const uint32_t before23 = row_sum_above(n23);
+    const uint32_t total23 = (uint32_t)__shfl((int)(before23 + n23), (int)(lane & 48u));  // lane 0 of the row sees all
+
+    // signs (cabac_writer.cpp:2860-2871)
+    const uint32_t n_nz = (uint32_t)__builtin_popcount(m_nz);
+    uint32_t n_signs = n_nz;
+    bool hidden = false;
+    if (n_nz && (flags & CABAC_TU_SIGN_HIDING)) {
+      const uint32_t hi_nz = 31u - (uint32_t)__builtin_clz(m_nz), lo_nz = (uint32_t)__builtin_ctz(m_nz);
+      if (hi_nz - lo_nz >= 4u) {
+        n_signs--;
+        hidden = l == lo_nz;
+      }
+    }
+
+    if (out) {
+      uint16_t *o1 = out + off + (uint32_t)__builtin_popcount(m_sig & m_ctx & above_mask) +
+                     (uint32_t)__builtin_popcount(m_nz & m_ctx & above_mask) + 2u * (uint32_t)__builtin_popcount(m_gt1 & m_ctx & above_mask);
+      if (n1) {
+        if (sig_coded) *o1++ = (uint16_t)rec_sig;
+        if (nzero) {
+          *o1++ = (uint16_t)rec_g1;
+          if (a > 1u) {
+            *o1++ = (uint16_t)rec_par;
+            *o1 = (uint16_t)rec_g2;
+          }
+        }
+      }
+      uint16_t *o2 = out + off + n_ctx_bins + before23;
+      for (uint32_t j = 0; j < ep.len1; j++) o2[j] = (uint16_t)((((ep.code1 >> (ep.len1 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+      o2 += ep.len1;
+      for (uint32_t j = 0; j < ep.len2; j++) o2[j] = (uint16_t)((((ep.code2 >> (ep.len2 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+      if (nzero && !hidden)
+        out[off + n_ctx_bins + total23 + (uint32_t)__builtin_popcount(m_nz & above_mask)] = (uint16_t)((c < 0 ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+    }
+    if (walk) {
+      off += n_ctx_bins + total23 + n_signs;
+      budget -= (int)n_ctx_bins;
+    }
+  }
+
+  if (tu_idx < n_tu && l == 0u) {
+    n_records[tu_idx] = off;
+    if (info_out) info_out[tu_idx] = info;
+  }
+}
+
+hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                           const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records) {
+  if (n_tu == 0) return hipSuccess;
+  hipLaunchKernelGGL(residual_kernel, dim3((n_tu + kRowsPerBlock - 1) / kRowsPerBlock), dim3(256), 0, st, n_tu, tus, coeff,
+                     rec_offset, n_records, info, records);
+  return hipGetLastError();
+}
+
+}  // namespace cabac

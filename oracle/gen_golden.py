@@ -153,6 +153,22 @@ def residual(ref):
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 
+    # bench.py's residual leg: md5 of the reference's records for the first blocks of the bench workload
+    from entropy_coding_amd import workload as W
+    tus, coeff, _ = W.build_residual_tiles(256)
+    k = 256
+    md5 = hashlib.md5()
+    total = 0
+    for d in tus[:k]:
+        w, h = 1 << int(d["log2_width"]), 1 << int(d["log2_height"])
+        c = coeff[int(d["coeff_offset"]): int(d["coeff_offset"]) + w * h].reshape(h, w)
+        r, _ = ref.residual_records(c, int(d["channel"]), int(d["flags"]))
+        md5.update(r.tobytes())
+        total += len(r)
+    with open(os.path.join(GOLD, "residual_bench.json"), "w") as f:
+        json.dump({"generator": "entropy_coding_amd.workload.build_residual_tiles(256)", "seed": W.RESIDUAL_SEED,
+                   "n_blocks": k, "n_records": total, "records_md5": md5.hexdigest()}, f, indent=1)
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "residual":

@@ -446,7 +446,8 @@ extern "C" {
 
 // flags: bit0 dep_quant, bit1 sign_data_hiding, bit2 transform-skip enabled in the SPS (max TS size 32),
 //        bit3 the cuCtx pointer is passed (info[1..4] = violatesLfnstConstrained[luma|chroma<<1], lfnstLastScanPos,
-//        violatesMtsCoeffConstraint, mtsLastScanPos).  comp: 0 Y, 1 Cb, 2 Cr.
+//        violatesMtsCoeffConstraint, mtsLastScanPos); bits 8..15: if non-zero, extended_precision_processing with
+//        this bit depth (SPS::getMaxLog2TrDynamicRange = min(20, depth + 6), slice.hpp:180-192).  comp: 0 Y, 1 Cb, 2 Cr.
 long ref_residual_records(int width, int height, int comp, int flags, const int32_t *coeff, uint16_t *out, long cap,
                           int32_t *info) {
   try {
@@ -455,6 +456,9 @@ long ref_residual_records(int width, int height, int comp, int flags, const int3
     rig.slice->m_signDataHidingEnabledFlag = (flags >> 1) & 1;
     rig.sps->m_transformSkipEnabledFlag = (flags >> 2) & 1;
     rig.sps->m_log2MaxTransformSkipBlockSize = 5;
+    const int depth = (flags >> 8) & 0xff;
+    rig.sps->m_spsRangeExtension.m_extendedPrecisionProcessingFlag = depth != 0;
+    rig.sps->m_bitDepths.recon[0] = rig.sps->m_bitDepths.recon[1] = depth ? depth : 10;
     TransformUnit tu;
     tu.initData();
     tu.chromaFormat = CHROMA_420;

@@ -231,8 +231,9 @@ class CodecLib:
         f.restype = ctypes.c_long
         f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, u16p, ctypes.c_long, i32p]
         info = np.zeros(8, np.int32)
-        assert max_log2_range == 15
-        n = f(w, h, 1 if chroma else 0, (flags & 7) | (8 if with_cuctx else 0), _ptr(coeff, i32p), _ptr(out, u16p), cap,
+        assert max_log2_range == 15 or 17 <= max_log2_range <= 20   # min(20, bit depth + 6) under extended precision
+        depth = 0 if max_log2_range == 15 else max_log2_range - 6
+        n = f(w, h, 1 if chroma else 0, (flags & 7) | (8 if with_cuctx else 0) | depth << 8, _ptr(coeff, i32p), _ptr(out, u16p), cap,
               _ptr(info, i32p))
         if n == -1:
             self.lib.ref_last_error.restype = ctypes.c_char_p

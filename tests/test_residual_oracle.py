@@ -72,6 +72,21 @@ def test_edge_blocks_match_reference():
         ref.residual_records(np.zeros((8, 8), np.int32))
 
 
+@needs_ref
+def test_extended_precision_dynamic_range_matches_reference():
+    """maxLog2TrDynamicRange > 15 (SPS extended_precision_processing_flag, slice.hpp:180-192) changes the escape code
+    length limits of encodeRemAbsEP (arith_codec.cpp:437-447)."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0xE0)
+    for rng_bits in (17, 18, 19, 20):
+        for w, h in [(4, 4), (16, 16), (8, 32)]:
+            for k in range(4):
+                c = H.random_block(rng, w, h, density=0.8, big=0.3, huge=0.3) * (1 << (rng_bits - 15))
+                want, _ = ref.residual_records(c, k & 1, 3, max_log2_range=rng_bits)
+                got, _, _ = orc.residual_records(c, k & 1, 3, max_log2_range=rng_bits)
+                assert np.array_equal(got, want), (rng_bits, w, h, k)
+
+
 def test_golden_blocks():
     orc = H.load_oracle()
     g = np.load(os.path.join(H.GOLDEN, "residual.npz"))
