@@ -25,8 +25,8 @@ struct cabac_hip_ctx {
   std::vector<int32_t> prof_kind;
   uint32_t prof_n = 0;
   // staging for the host-pointer entry points (grown on demand)
-  void *d_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[5] = {0, 0, 0, 0, 0};
+  void *d_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [5]: scratch of the residual binariser
+  size_t d_cap[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -141,7 +141,7 @@ void cabac_hip_destroy(cabac_hip_ctx *c) {
   if (!c) return;
   DeviceGuard g(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < 6; i++)
     if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -444,9 +444,11 @@ int cabac_hip_residual_device(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_de
   if (!c || (n_tu && (!d_tu || !d_coeff || !d_n_records || (d_records && !d_rec_offset))))
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
+  if (int rc = ensure(c, 5, cabac::residual_scratch_bytes(n_tu))) return rc;
   Bracket br = bracket_for(c, 5);
   HIP_TRY(c, hipEventRecord(br.a, c->stream));
-  HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records));
+  HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records,
+                                    c->d_buf[5]));
   HIP_TRY(c, hipEventRecord(br.b, c->stream));
   c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;

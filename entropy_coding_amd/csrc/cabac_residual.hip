@@ -17,8 +17,12 @@
 // position inside the coefficient group, one loop iteration per coefficient group in coding order; row-wide
 // sums come from ballots + popcounts, the output offsets from a 4-step DPP suffix scan.  The budget, the state
 // and the write offset are carried from group to group as row-uniform values.
+// Rows of one wave should run the same number of groups, so a pre-pass (class_hist / class_scatter) orders the
+// blocks by their group count into a permutation held in library scratch; the main kernel takes its blocks
+// from that list.  The dependent-quantisation state machine is linear over GF(2) — (s1, s0) -> (parity ^ s0, s1)
+// — so the state on entry to every position is two masked popcounts of the group's parity bits, not a walk.
 // Reads 4 B per coefficient (plus template re-reads that hit L1/L2), writes 2 B per bin: HBM-bound by
-// construction; no LDS, no MFMA.
+// construction; no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -125,14 +129,63 @@ constexpr uint32_t kRowsPerBlock = 16;  // 256 threads
 
 }  // namespace
 
+// log2 of the number of coefficient groups of a block (0..6), 7 for a descriptor the kernel rejects
+__device__ __forceinline__ uint32_t size_class(const cabac_tu_desc &d) {
+  const uint32_t lw = d.log2_width, lh = d.log2_height;
+  if (lw > 6u || lh > 6u) return 7u;
+  const uint32_t coded = (lw < 5u ? lw : 5u) + (lh < 5u ? lh : 5u);  // log2 of the coded area
+  return coded > 4u ? coded - 4u : 0u;                               // groups hold 16 (or all, if fewer) coefficients
+}
+
+constexpr uint32_t kClasses = 8;
+// scratch layout (uint32): [0..7] blocks per class, [8..15] scatter cursors, [16..] permutation (padded per class)
+constexpr uint32_t kScratchHeader = 16;
+
+__global__ __launch_bounds__(256) void class_hist(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
+                                                   uint32_t *__restrict__ scratch) {
+  __shared__ uint32_t h[kClasses];
+  if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n_tu) atomicAdd(&h[size_class(tus[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x < kClasses && h[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], h[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t class_base(const uint32_t *scratch, uint32_t cls) {  // start of a class, 16-aligned
+  uint32_t base = 0;
+  for (uint32_t k = kClasses; k-- > cls + 1u;) base += (scratch[k] + kRowsPerBlock - 1u) & ~(kRowsPerBlock - 1u);
+  return base;  // largest blocks first: the long-running workgroups start first
+}
+
+__global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
+                                                      uint32_t *__restrict__ scratch) {
+  __shared__ uint32_t h[kClasses], start[kClasses];
+  if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t cls = 0, rank = 0;
+  if (i < n_tu) {
+    cls = size_class(tus[i]);
+    rank = atomicAdd(&h[cls], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kClasses)
+    start[threadIdx.x] = class_base(scratch, threadIdx.x) + (h[threadIdx.x] ? atomicAdd(&scratch[kClasses + threadIdx.x], h[threadIdx.x]) : 0u);
+  __syncthreads();
+  if (i < n_tu) scratch[kScratchHeader + start[cls] + rank] = i;
+}
+
+template <bool kWrite>
 __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                                         const int32_t *__restrict__ coeff_all,
                                                         const uint64_t *__restrict__ rec_offset,
                                                         uint32_t *__restrict__ n_records,
                                                         uint32_t *__restrict__ info_out,
-                                                        uint16_t *__restrict__ records) {
+                                                        uint16_t *__restrict__ records,
+                                                        const uint32_t *__restrict__ perm) {
   const uint32_t lane = threadIdx.x & 63u, l = lane & 15u, row_shift = lane & 48u;
-  const uint32_t tu_idx = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 4);
+  const uint32_t tu_idx = perm[blockIdx.x * kRowsPerBlock + (threadIdx.x >> 4)];  // 0xFFFFFFFF: padding
   bool live = tu_idx < n_tu;
 
   // ---- geometry (row-uniform) -------------------------------------------------------------------
@@ -166,37 +219,38 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   const uint8_t *grid = c_diag.grid[lwg][lhg];
   const bool lane_in_cg = l < cg_size;
 
-  // ---- sweep 1: last significant position and the per-group significance map ---------------------
-  uint32_t max_cg = n_cg;
-  max_cg = max(max_cg, (uint32_t)__shfl_xor((int)max_cg, 16));
-  max_cg = max(max_cg, (uint32_t)__shfl_xor((int)max_cg, 32));
-  max_cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_cg);
-  uint64_t sig_map = 0;  // bit gy * wg + gx
+  // ---- sweep 1: the last significant position, searched from the end of the scan ----------------------
   int last = -1;
-  for (uint32_t cg = 0; cg < max_cg; cg++) {
-    const bool on = cg < n_cg && lane_in_cg;
-    int32_t c = 0;
-    uint32_t gpos = 0;
-    if (cg < n_cg) gpos = grid[cg];
-    const uint32_t gx = gpos & 15u, gy = gpos >> 4;
-    if (on) c = coeff[(((gy << cgh_l2) + iy) << lw) + (gx << cgw_l2) + ix];
-    const uint32_t nz = row_bits(c != 0, row_shift);
-    if (nz) {
-      last = (int)((cg << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
-      sig_map |= 1ull << (gy * wg + gx);
+  {
+    int cg = (int)n_cg - 1;  // row-uniform; the rows of a wave normally share n_cg (class order)
+    int top = cg;
+    top = max(top, __shfl_xor(top, 16));
+    top = max(top, __shfl_xor(top, 32));
+    top = __builtin_amdgcn_readfirstlane(top);
+    for (int k = top; k >= 0; k--) {
+      const bool searching = last < 0 && k < (int)n_cg;
+      if (__ballot(searching) == 0ull) break;
+      int32_t c = 0;
+      if (searching && lane_in_cg) {
+        const uint32_t gpos = grid[k];
+        c = coeff[((((gpos >> 4) << cgh_l2) + iy) << lw) + ((gpos & 15u) << cgw_l2) + ix];
+      }
+      const uint32_t nz = row_bits(c != 0, row_shift);
+      if (searching && nz) last = (int)(((uint32_t)k << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
     }
   }
+  uint64_t sig_map = 0;  // bit gy * wg + gx, filled in as sweep 2 meets the groups (right and below come first)
   const bool empty = live && last < 0;
   live = live && !empty;
 
-  uint16_t *out = (records && live) ? records + rec_offset[tu_idx] : nullptr;
+  uint16_t *out = (kWrite && live) ? records + rec_offset[tu_idx] : nullptr;
   uint32_t off = 0;  // records produced so far (row-uniform)
   uint32_t info = live ? (uint32_t)last : (bad ? CABAC_TU_INFO_BAD_DESC : empty ? CABAC_TU_INFO_EMPTY : 0u);
 
   // ---- ts_flag and the last position ------------------------------------------------------------------
   if (live) {
     if (flags & CABAC_TU_TS_FLAG) {
-      if (out && l == 0u) out[0] = (uint16_t)CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma);
+      if (kWrite && l == 0u) out[0] = (uint16_t)CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma);
       off = 1;
     }
     const uint32_t lcg = (uint32_t)last >> cg_l2;
@@ -210,7 +264,7 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     const uint32_t gix = group_idx(px), giy = group_idx(py);
     const uint32_t nx = gix + (gix < group_idx(we - 1u) ? 1u : 0u), ny = giy + (giy < group_idx(he - 1u) ? 1u : 0u);
     const uint32_t sx = gix > 3u ? (gix - 2u) >> 1 : 0u, sy = giy > 3u ? (giy - 2u) >> 1 : 0u;
-    if (out) {
+    if (kWrite) {
       if (l < nx) out[off + l] = (uint16_t)((l < gix ? CABAC_REC_BIN : 0u) | (CABAC_CTX_LAST_X(chroma) + off_x + (l >> sh_x)));
       if (l < ny) out[off + nx + l] = (uint16_t)((l < giy ? CABAC_REC_BIN : 0u) | (CABAC_CTX_LAST_Y(chroma) + off_y + (l >> sh_y)));
       if (l < sx) out[off + nx + ny + l] = (uint16_t)(((((px - min_in_group(gix)) >> (sx - 1u - l)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
@@ -220,45 +274,31 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   }
 
   // ---- sweep 2: the coefficient groups in coding order ----------------------------------------------
-  const uint32_t trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u;  // cabac_writer.cpp:2482
-  const bool any_dq = __ballot(live && trans != 0u) != 0ull;
-  int budget = (int)((we * he * 28u) >> 4);  // cabac_writer.cpp:2485-2489
+  const bool dq = live && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
+  int budget = (int)((we * he * 28u) >> 4);              // cabac_writer.cpp:2485-2489
   uint32_t state = 0;
   const int last_cg = live ? (last >> cg_l2) : -1;
   int top_cg = last_cg;
   top_cg = max(top_cg, __shfl_xor(top_cg, 16));
   top_cg = max(top_cg, __shfl_xor(top_cg, 32));
   top_cg = __builtin_amdgcn_readfirstlane(top_cg);
-  const uint32_t sig_set_base = chroma;  // SigFlag[chType + 2 * max(0, state - 1)]
 
   for (int cg = top_cg; cg >= 0; cg--) {
     const bool row_on = cg <= last_cg;  // this row still has groups to code
     const uint32_t gpos = row_on ? grid[cg] : 0u;
     const uint32_t gx = gpos & 15u, gy = gpos >> 4;
     const uint32_t gbit = gy * wg + gx;
-    const bool coded_group = (sig_map >> gbit) & 1ull;
-    const bool has_flag = row_on && cg != last_cg && cg != 0;
-    if (has_flag) {
-      const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
-      const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
-      if (out && l == 0u)
-        out[off] = (uint16_t)((coded_group ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)));
-      off += 1u;
-    }
-    const bool walk = row_on && (coded_group || cg == 0 || cg == last_cg);  // residual_coding_subblock goes past its early return
-    if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
-
     const int lo = cg << cg_l2;
     const int first = cg == last_cg ? last : lo + (int)cg_size - 1;
     const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
     const int pos = lo + (int)l;
-    const bool act = walk && lane_in_cg && pos <= first;
+    const bool in_range = row_on && lane_in_cg && pos <= first;
     const uint32_t x = (gx << cgw_l2) + ix, y = (gy << cgh_l2) + iy, diag = x + y;
 
     // coefficient and its template (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176)
     int32_t c = 0;
     int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
-    if (act) {
+    if (in_range) {
       const int32_t *p = coeff + (y << lw) + x;
       c = p[0];
       auto add = [&](int32_t v) {
@@ -279,9 +319,25 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     }
     const uint32_t a = (uint32_t)(c < 0 ? -c : c);
     const bool nzero = c != 0;
+    const uint32_t m_nz = row_bits(nzero, row_shift);
+
+    // coded_sub_block_flag (cabac_writer.cpp:2733-2743); the group's neighbours to the right and below were met earlier
+    const bool coded_group = m_nz != 0u;
+    if (row_on && coded_group) sig_map |= 1ull << gbit;
+    const bool has_flag = row_on && cg != last_cg && cg != 0;
+    if (has_flag) {
+      if (kWrite && l == 0u) {
+        const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
+        const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
+        out[off] = (uint16_t)((coded_group ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)));
+      }
+      off += 1u;
+    }
+    const bool walk = row_on && (coded_group || cg == 0);  // residual_coding_subblock goes past its early return
+    if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
+    const bool act = walk && in_range;
 
     // which bins exist, and how far the context-bin budget reaches
-    const uint32_t m_nz = row_bits(nzero, row_shift);
     const uint32_t above_mask = ~0u << (l + 1u);  // positions coded before this one
     const bool sig_coded = act && !(pos == infer && (m_nz & above_mask) == 0u);
     const uint32_t m_sig = row_bits(sig_coded, row_shift);
@@ -293,51 +349,41 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     const uint32_t n_ctx_bins = (uint32_t)__builtin_popcount(m_sig & m_ctx) + (uint32_t)__builtin_popcount(m_nz & m_ctx) +
                                 2u * (uint32_t)__builtin_popcount(m_gt1 & m_ctx);
 
-    // dependent-quantisation state on entry to each position (cabac_writer.cpp:2787, :2837)
+    // Dependent-quantisation state on entry to each position (cabac_writer.cpp:2787, :2837).  The transition
+    // (s1, s0) -> (parity ^ s0, s1) makes s1 after t steps the XOR of every second parity before it, so with the
+    // positions top .. 0 of the group coded in that order, position l (step t = top - l) enters with
+    //   s1 = xor of parity[l+1], parity[l+3], ... ^ (t odd ? s0 : s1 at group entry),   s0 = the same one step earlier.
     uint32_t my_state = 0;
-    if (any_dq) {
-      const uint32_t m_act = row_bits(act, row_shift);
-      const uint32_t m_par = row_bits(act && (a & 1u), row_shift);
-      uint32_t st = state;
-#pragma unroll
-      for (int i = 15; i >= 0; i--) {
-        my_state = (int)l == i ? st : my_state;
-        const uint32_t nxt = (trans >> ((st << 2) + (((m_par >> i) & 1u) << 1))) & 3u;
-        st = ((m_act >> i) & 1u) ? nxt : st;
+    {
+      const uint32_t m_par = row_bits(dq && act && (a & 1u), row_shift);
+      const uint32_t top = (uint32_t)(first - lo), t = top - l;
+      const uint32_t s1 = state >> 1, s0 = state & 1u;
+      const uint32_t e1 = (uint32_t)__builtin_popcount((m_par >> (l + 1u)) & 0x5555u) & 1u;
+      const uint32_t e0 = (uint32_t)__builtin_popcount((m_par >> (l + 2u)) & 0x5555u) & 1u;
+      my_state = ((e1 ^ ((t & 1u) ? s0 : s1)) << 1) | (e0 ^ ((t & 1u) ? s1 : s0));
+      if (walk) {  // state after the top + 1 steps of this group
+        const uint32_t x1 = (uint32_t)__builtin_popcount(m_par & 0x5555u) & 1u, x0 = (uint32_t)__builtin_popcount(m_par & 0xAAAAu) & 1u;
+        const uint32_t n = top + 1u;
+        state = ((x1 ^ ((n & 1u) ? s0 : s1)) << 1) | (x0 ^ ((n & 1u) ? s1 : s0));
       }
-      state = st;
+      if (!dq) my_state = 0;
     }
 
-    // pass 1 records of this position
-    uint32_t rec_sig = 0, rec_g1 = 0, rec_par = 0, rec_g2 = 0, n1 = 0;
+    // pass 2 (remainder of a context-coded level) or pass 3 (whole level in bypass mode): one escape code per position
+    uint32_t ep_value = 0, ep_rice = 0;
+    bool has_ep = false;
     if (ctx_mode) {
-      uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + (diag < 2u ? 4u : 0u);
-      if (chroma == 0u) ofs += diag < 5u ? 4u : 0u;
-      const uint32_t set = sig_set_base + 2u * (my_state > 1u ? my_state - 1u : 0u);
-      rec_sig = (nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_FLAG(set) + ofs);
-      uint32_t aofs = 0;
-      if (pos != last) {  // ctxOffsetAbs, context_modelling.hpp:131-143
-        aofs = (uint32_t)min(sum_clip - n_tmpl, 4) + 1u;
-        if (diag == 0u) aofs += chroma ? 5u : 15u;
-        else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
-      }
-      const uint32_t rem = a - 2u;  // only read when a > 1
-      rec_g1 = (a > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(2u + chroma) + aofs);
-      rec_par = ((rem & 1u) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_PAR_FLAG(chroma) + aofs);
-      rec_g2 = ((rem >> 1) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(chroma) + aofs);
-      n1 = (sig_coded ? 1u : 0u) + (nzero ? (a > 1u ? 3u : 1u) : 0u);
-    }
-
-    // pass 2 (remainder of a context-coded level) or pass 3 (whole level in bypass mode)
-    EpCode ep = {0, 0, 0, 0};
-    if (ctx_mode) {
-      if (a >= 4u) ep = rem_abs_code((a - 4u) >> 1, rice_of(sum_abs, 4), max_log2);
+      has_ep = a >= 4u;
+      ep_value = (a - 4u) >> 1;
+      ep_rice = rice_of(sum_abs, 4);
     } else if (act) {
-      const uint32_t rice = rice_of(sum_abs, 0);
-      const uint32_t pos0 = (my_state < 2u ? 1u : 2u) << rice;
-      const uint32_t rem = a == 0u ? pos0 : (a <= pos0 ? a - 1u : a);
-      ep = rem_abs_code(rem, rice, max_log2);
+      has_ep = true;
+      ep_rice = rice_of(sum_abs, 0);
+      const uint32_t pos0 = (my_state < 2u ? 1u : 2u) << ep_rice;
+      ep_value = a == 0u ? pos0 : (a <= pos0 ? a - 1u : a);
     }
+    EpCode ep = {0, 0, 0, 0};
+    if (has_ep) ep = rem_abs_code(ep_value, ep_rice, max_log2);
     const uint32_t n23 = ep.len1 + ep.len2;
     const uint32_t before23 = row_sum_above(n23);
     const uint32_t total23 = (uint32_t)__shfl((int)(before23 + n23), (int)(lane & 48u));  // lane 0 of the row sees all
@@ -354,16 +400,25 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
       }
     }
 
-    if (out) {
-      uint16_t *o1 = out + off + (uint32_t)__builtin_popcount(m_sig & m_ctx & above_mask) +
-                     (uint32_t)__builtin_popcount(m_nz & m_ctx & above_mask) + 2u * (uint32_t)__builtin_popcount(m_gt1 & m_ctx & above_mask);
-      if (n1) {
-        if (sig_coded) *o1++ = (uint16_t)rec_sig;
+    if (kWrite && act) {
+      if (ctx_mode) {
+        uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + (diag < 2u ? 4u : 0u);
+        if (chroma == 0u) ofs += diag < 5u ? 4u : 0u;
+        const uint32_t set = chroma + 2u * (my_state > 1u ? my_state - 1u : 0u);  // SigFlag[chType + 2 * max(0, state - 1)]
+        uint32_t aofs = 0;
+        if (pos != last) {  // ctxOffsetAbs, context_modelling.hpp:131-143
+          aofs = (uint32_t)min(sum_clip - n_tmpl, 4) + 1u;
+          if (diag == 0u) aofs += chroma ? 5u : 15u;
+          else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
+        }
+        uint16_t *o1 = out + off + spent_before;  // every position above a context-coded one is context coded
+        if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_FLAG(set) + ofs));
         if (nzero) {
-          *o1++ = (uint16_t)rec_g1;
+          *o1++ = (uint16_t)((a > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(2u + chroma) + aofs));
           if (a > 1u) {
-            *o1++ = (uint16_t)rec_par;
-            *o1 = (uint16_t)rec_g2;
+            const uint32_t rem = a - 2u;
+            *o1++ = (uint16_t)(((rem & 1u) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_PAR_FLAG(chroma) + aofs));
+            *o1 = (uint16_t)(((rem >> 1) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(chroma) + aofs));
           }
         }
       }
@@ -386,11 +441,31 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   }
 }
 
+size_t residual_scratch_bytes(uint32_t n_tu) {
+  return sizeof(uint32_t) * (kScratchHeader + (size_t)n_tu + kClasses * kRowsPerBlock);
+}
+
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
-                           const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records) {
+                           const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
+                           void *scratch) {
   if (n_tu == 0) return hipSuccess;
-  hipLaunchKernelGGL(residual_kernel, dim3((n_tu + kRowsPerBlock - 1) / kRowsPerBlock), dim3(256), 0, st, n_tu, tus, coeff,
-                     rec_offset, n_records, info, records);
+  // blocks ordered by group count: [counts | cursors | permutation, 0xFFFFFFFF where a class is padded to 16 rows]
+  uint32_t *s32 = static_cast<uint32_t *>(scratch);
+  const uint32_t rows = n_tu + kClasses * kRowsPerBlock;  // upper bound of the padded list
+  hipError_t e = hipMemsetAsync(s32, 0, sizeof(uint32_t) * kScratchHeader, st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
+  if (e != hipSuccess) return e;
+  const uint32_t g = (n_tu + 255u) / 256u;
+  hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
+  hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
+  const dim3 grid(rows / kRowsPerBlock);
+  if (records)
+    hipLaunchKernelGGL(residual_kernel<true>, grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info, records,
+                       s32 + kScratchHeader);
+  else
+    hipLaunchKernelGGL(residual_kernel<false>, grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info, records,
+                       s32 + kScratchHeader);
   return hipGetLastError();
 }
 
