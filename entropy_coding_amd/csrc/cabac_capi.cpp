@@ -454,4 +454,52 @@ int cabac_hip_residual_device(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_de
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_residual_batch(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                             uint64_t n_coeff_total, uint64_t *offsets, uint32_t *info, uint16_t *records,
+                             uint64_t records_capacity) {
+  if (!c || !offsets || (n_tu && (!tus || !coeff))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  offsets[0] = 0;
+  if (n_tu == 0) return CABAC_HIP_OK;
+  for (uint32_t t = 0; t < n_tu; t++) {
+    if (tus[t].log2_width > 6 || tus[t].log2_height > 6) continue;  // flagged by the kernel, reads nothing
+    const uint64_t n = uint64_t(1) << (tus[t].log2_width + tus[t].log2_height);
+    if (tus[t].coeff_offset > n_coeff_total || n > n_coeff_total - tus[t].coeff_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "coefficients out of range");
+  }
+  DeviceGuard g(c->device);
+  int rc;
+  // staging: [0] descriptors, [1] coefficients, [3] record offsets, [4] counts then info, [2] records
+  if ((rc = ensure(c, 0, n_tu * sizeof(cabac_tu_desc)))) return rc;
+  if ((rc = ensure(c, 1, n_coeff_total * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, 3, n_tu * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, 4, 2 * size_t(n_tu) * sizeof(uint32_t)))) return rc;
+  uint32_t *d_cnt = static_cast<uint32_t *>(c->d_buf[4]), *d_info = d_cnt + n_tu;
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], tus, n_tu * sizeof(cabac_tu_desc), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], coeff, n_coeff_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_residual_device(c, n_tu, (const cabac_tu_desc *)c->d_buf[0], (const int32_t *)c->d_buf[1], nullptr, d_cnt,
+                                 d_info, nullptr);
+  if (rc) return rc;
+  std::vector<uint32_t> cnt(2 * size_t(n_tu));
+  HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int status = CABAC_HIP_OK;
+  for (uint32_t t = 0; t < n_tu; t++) {
+    offsets[t + 1] = offsets[t] + cnt[t];
+    if (info) info[t] = cnt[n_tu + t];
+    if (cnt[n_tu + t] & (CABAC_TU_INFO_EMPTY | CABAC_TU_INFO_BAD_DESC)) status = CABAC_HIP_ERR_SUBSTREAM;
+  }
+  if (status) c->last_error = "empty block or bad descriptor (see info[])";
+  if (!records) return status;
+  if (records_capacity < offsets[n_tu]) return fail(c, CABAC_HIP_ERR_INVALID, "records_capacity too small");
+  if (offsets[n_tu] == 0) return status;
+  if ((rc = ensure(c, 2, offsets[n_tu] * sizeof(uint16_t)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[3], offsets, n_tu * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_residual_device(c, n_tu, (const cabac_tu_desc *)c->d_buf[0], (const int32_t *)c->d_buf[1],
+                                 (const uint64_t *)c->d_buf[3], d_cnt, d_info, (uint16_t *)c->d_buf[2]);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(records, c->d_buf[2], offsets[n_tu] * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return status;
+}
+
 }  // extern "C"

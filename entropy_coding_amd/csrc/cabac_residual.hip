@@ -295,28 +295,10 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     const bool in_range = row_on && lane_in_cg && pos <= first;
     const uint32_t x = (gx << cgw_l2) + ix, y = (gy << cgh_l2) + iy, diag = x + y;
 
-    // coefficient and its template (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176)
+    // the coefficient; its template is fetched below, once it is known that somebody codes this group
     int32_t c = 0;
-    int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
-    if (in_range) {
-      const int32_t *p = coeff + (y << lw) + x;
-      c = p[0];
-      auto add = [&](int32_t v) {
-        const int a = v < 0 ? -v : v;
-        sum_abs += a;
-        sum_clip += min(a, 4 + (a & 1));
-        n_tmpl += a != 0;
-      };
-      if (x + 1u < w) {
-        add(p[1]);
-        if (x + 2u < w) add(p[2]);
-        if (y + 1u < h) add(p[w + 1u]);
-      }
-      if (y + 1u < h) {
-        add(p[w]);
-        if (y + 2u < h) add(p[2u * w]);
-      }
-    }
+    const int32_t *p = coeff + (y << lw) + x;
+    if (in_range) c = p[0];
     const uint32_t a = (uint32_t)(c < 0 ? -c : c);
     const bool nzero = c != 0;
     const uint32_t m_nz = row_bits(nzero, row_shift);
@@ -336,6 +318,29 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     const bool walk = row_on && (coded_group || cg == 0);  // residual_coding_subblock goes past its early return
     if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
     const bool act = walk && in_range;
+    if (__ballot(walk) == 0ull) continue;  // no row of this wave codes anything here beyond the group flag
+
+    // template of the position (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176): five
+    // neighbours to the right and below, absent ones count as zero.  Loads are unconditional from clamped
+    // addresses (no exec juggling); an absent neighbour is zeroed afterwards.
+    int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
+    if (act) {
+      const bool x1 = x + 1u < w, x2 = x + 2u < w, y1 = y + 1u < h, y2 = y + 2u < h;
+      const uint32_t dx1 = x1 ? 1u : 0u, dx2 = x2 ? 2u : 0u, dy1 = y1 ? w : 0u, dy2 = y2 ? 2u * w : 0u;
+      const int32_t v0 = p[dx1], v1 = p[dx2], v2 = p[dy1 + dx1], v3 = p[dy1], v4 = p[dy2];
+      auto add = [&](int32_t v, bool present) {
+        int a = v < 0 ? -v : v;
+        a = present ? a : 0;
+        sum_abs += a;
+        sum_clip += min(a, 4 + (a & 1));
+        n_tmpl += a != 0;
+      };
+      add(v0, x1);
+      add(v1, x2);
+      add(v2, x1 && y1);
+      add(v3, y1);
+      add(v4, y2);
+    }
 
     // which bins exist, and how far the context-bin budget reaches
     const uint32_t above_mask = ~0u << (l + 1u);  // positions coded before this one

@@ -184,6 +184,48 @@ std::vector<uint64_t> HipBatch::estimate(const std::vector<EstimateJob> &jobs) {
   return cost;
 }
 
+HipBatch::ResidualResult HipBatch::residual(const std::vector<ResidualBlock> &blocks) {
+  ResidualResult r;
+  const uint32_t n = uint32_t(blocks.size());
+  r.offsets.assign(size_t(n) + 1, 0);
+  r.info.assign(n, 0);
+  if (n == 0) return r;
+  std::vector<cabac_tu_desc> tus(n);
+  uint64_t total = 0;
+  for (uint32_t t = 0; t < n; t++) {
+    const ResidualBlock &b = blocks[t];
+    unsigned lw = 0, lh = 0;
+    while ((1u << lw) < b.width) lw++;
+    while ((1u << lh) < b.height) lh++;
+    if (!b.coeff || (1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6)
+      throw Exception("residual: block sizes must be powers of two up to 64");
+    tus[t] = cabac_tu_desc{};
+    tus[t].coeff_offset = total;
+    tus[t].log2_width = uint8_t(lw);
+    tus[t].log2_height = uint8_t(lh);
+    tus[t].channel = b.chroma ? 1 : 0;
+    tus[t].flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
+                           (b.tsFlag ? CABAC_TU_TS_FLAG : 0u));
+    tus[t].max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
+    total += uint64_t(b.width) * b.height;
+  }
+  std::vector<int32_t> coeff(total);
+  for (uint32_t t = 0; t < n; t++)
+    std::memcpy(coeff.data() + tus[t].coeff_offset, blocks[t].coeff, size_t(blocks[t].width) * blocks[t].height * sizeof(int32_t));
+  int rc = cabac_hip_residual_batch(handle(), n, tus.data(), coeff.data(), total, r.offsets.data(), r.info.data(), nullptr, 0);
+  if (rc == CABAC_HIP_ERR_SUBSTREAM) {
+    for (uint32_t t = 0; t < n; t++)
+      if (r.info[t] & CABAC_TU_INFO_EMPTY) throw Exception("Coefficient coding called for empty TU");
+  }
+  check_status(m_ctx, rc, "cabac_hip_residual_batch");
+  r.records.assign(size_t(r.offsets[n]) ? size_t(r.offsets[n]) : 1, 0);
+  rc = cabac_hip_residual_batch(m_ctx, n, tus.data(), coeff.data(), total, r.offsets.data(), r.info.data(), r.records.data(),
+                                r.records.size());
+  check_status(m_ctx, rc, "cabac_hip_residual_batch");
+  r.records.resize(size_t(r.offsets[n]));
+  return r;
+}
+
 void HipBatch::decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
                       std::vector<uint32_t> *bitsRead) {
   const uint32_t n = uint32_t(jobs.size());

@@ -135,6 +135,26 @@ public:
   };
   std::vector<uint64_t> estimate(const std::vector<EstimateJob> &jobs);
 
+  // Residual binariser: the bin records CABACWriter::residual_coding (cabac_writer.cpp:2424-2525) would ask its bin
+  // encoder for, for many transform blocks in one launch.  Regular residual coding only (no transform-skip residual,
+  // no SBT/MTS zero-out, no range-extension Rice derivation).  Throws Exception("Coefficient coding called for empty
+  // TU") for an all-zero block, as the reference's CHECK does (cabac_writer.cpp:2458).
+  struct ResidualBlock {
+    const int32_t *coeff;  // width * height coefficients, raster (TransformUnit::getCoeffs(compID).buf)
+    unsigned width, height;
+    bool chroma;           // toChannelType(compID) == CHANNEL_TYPE_CHROMA
+    bool depQuant;         // Slice::getDepQuantEnabledFlag
+    bool signHiding;       // Slice::getSignDataHidingEnabledFlag
+    bool tsFlag;           // TU::isTSAllowed: code transform_skip_flag = 0 first
+    int maxLog2TrDynamicRange = 15;
+  };
+  struct ResidualResult {
+    std::vector<uint16_t> records;   // all blocks back to back
+    std::vector<uint64_t> offsets;   // n + 1 entries
+    std::vector<uint32_t> info;      // scanPosLast | CABAC_TU_INFO_MTS_VIOLATION
+  };
+  ResidualResult residual(const std::vector<ResidualBlock> &blocks);
+
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
   // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned

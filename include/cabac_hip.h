@@ -290,6 +290,15 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
                              const uint16_t *records, uint64_t n_records_total,
                              uint64_t *frac_bits, uint32_t *flags);
 
+/* Host-pointer form of cabac_hip_residual_device (synchronous, both passes).  `offsets` receives n_tu + 1 record
+ * offsets (block t's records are records[offsets[t] .. offsets[t+1])); n_records/info as on the device, info may
+ * be NULL.  If `records` is NULL or records_capacity is less than offsets[n_tu], only the sizes are produced
+ * (status OK in the first case, CABAC_HIP_ERR_INVALID in the second).  Blocks flagged CABAC_TU_INFO_EMPTY /
+ * CABAC_TU_INFO_BAD_DESC produce no records and make the call return CABAC_HIP_ERR_SUBSTREAM.              */
+int cabac_hip_residual_batch(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                             uint64_t n_coeff_total, uint64_t *offsets, uint32_t *info, uint16_t *records,
+                             uint64_t records_capacity);
+
 /* ---- per-launch timing (HIP events on the ctx stream) ----------------
  * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize/estimate device call is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;

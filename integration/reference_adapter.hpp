@@ -19,6 +19,9 @@
 #define CABAC_HIP_REFERENCE_ADAPTER_HPP
 
 #include "arith_codec.hpp"  // reference
+#include "coding_structure.hpp"  // reference (TransformUnit, CodingStructure)
+#include "context_modelling.hpp"  // reference (CUCtx)
+#include "unit_tools.hpp"  // reference (TU::isTSAllowed)
 #include "cabac_hip_host.hpp"
 
 // the reference's CHECK/THROW name `Exception` unqualified (type_def.hpp:319-326); inside this
@@ -161,6 +164,107 @@ public:
 
 private:
   BitEstimatorHip m_est;
+};
+
+// CABACWriter::residual_coding (cabac_writer.cpp:2424-2525) with the binarisation done on the GPU: same arguments,
+// same bins into the bin encoder, same CUCtx side effects.  `residual_coding` is the drop-in for one block (one launch
+// per call: for checking, not for speed); `queue` + `flush` is the shape a writer uses — blocks queued while the
+// syntax walk runs, one launch for all of them, each block's bins handed to the encoder in order.
+// Covered: regular residual coding.  Not covered (throws): transform-skip residual coding (residual_codingTS), the
+// SBT/MTS zero-out of last_sig_coeff, and the range extensions (Rice extension, persistent Rice adaptation).
+class ResidualCoderHipRef {
+public:
+  ResidualCoderHipRef(HipBatch &batch, EntropyCoding::BinEncIf &enc) : m_batch(batch), m_enc(enc) {}
+
+  void residual_coding(const Common::TransformUnit &tu, Common::ComponentID compID, Common::CUCtx *cuCtx) {
+    queue(tu, compID, cuCtx);
+    flush();
+  }
+
+  void queue(const Common::TransformUnit &tu, Common::ComponentID compID, Common::CUCtx *cuCtx) {
+    using namespace Common;
+    if (compID == COMPONENT_Cr && tu.jointCbCr == 3) return;  // cabac_writer.cpp:2428-2430
+    Item it;
+    it.tsAllowed = TU::isTSAllowed(tu, compID);                // ts_flag, cabac_writer.cpp:2527-2534
+    it.tsFlag = tu.mtsIdx[compID] == MTS_SKIP ? 1 : 0;
+    it.chroma = !isLuma(compID);
+    const SPS &sps = *tu.cs->sps;
+    HIPREF_CHECK(tu.mtsIdx[compID] == MTS_SKIP && !tu.cs->slice->getTSResidualCodingDisabledFlag(),
+                 "transform-skip residual coding is not covered by the GPU binariser");
+    HIPREF_CHECK(sps.getSpsRangeExtension().getRrcRiceExtensionEnableFlag() ||
+                     sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag(),
+                 "range-extension Rice derivation is not covered by the GPU binariser");
+    HIPREF_CHECK(sps.getUseMTS() && tu.cu->sbtInfo != 0, "SBT zero-out is not covered by the GPU binariser");
+    const CompArea &blk = tu.blocks[compID];
+    it.width = blk.width;
+    it.height = blk.height;
+    it.cuCtx = cuCtx;
+    it.notSkip = tu.mtsIdx[compID] != MTS_SKIP;
+    const TCoeff *c = tu.getCoeffs(compID).buf;
+    it.coeff.assign(c, c + size_t(blk.width) * blk.height);
+    it.depQuant = tu.cs->slice->getDepQuantEnabledFlag();
+    it.signHiding = tu.cs->slice->getSignDataHidingEnabledFlag();
+    it.maxLog2 = sps.getMaxLog2TrDynamicRange(toChannelType(compID));
+    m_items.push_back(std::move(it));
+  }
+
+  void flush() {
+    using namespace Common;
+    std::vector<HipBatch::ResidualBlock> blocks;
+    for (const Item &it : m_items) {
+      HipBatch::ResidualBlock b;
+      b.coeff = it.coeff.data();
+      b.width = it.width;
+      b.height = it.height;
+      b.chroma = it.chroma;
+      b.depQuant = it.depQuant;
+      b.signHiding = it.signHiding;
+      b.tsFlag = false;  // coded below through the encoder: its value need not be 0 here
+      b.maxLog2TrDynamicRange = it.maxLog2;
+      blocks.push_back(b);
+    }
+    HipBatch::ResidualResult r;
+    try {
+      r = m_batch.residual(blocks);
+    } catch (const EntropyCodingAMD::Exception &e) {
+      m_items.clear();
+      HIPREF_THROW(e.what());
+    }
+    for (size_t t = 0; t < m_items.size(); t++) {
+      const Item &it = m_items[t];
+      if (it.tsAllowed) m_enc.encodeBin(it.tsFlag, Ctx::TransformSkipFlag(it.chroma ? 1 : 0));
+      for (uint64_t k = r.offsets[t]; k < r.offsets[t + 1]; k++) {
+        const unsigned id = r.records[k] & CABAC_REC_ID_MASK, bin = r.records[k] >> 15;
+        if (id == CABAC_REC_EP) m_enc.encodeBinEP(bin);
+        else m_enc.encodeBin(bin, id);
+      }
+      if (CUCtx *cu = it.cuCtx) {  // cabac_writer.cpp:2461-2477, :2519-2522
+        const int last = int(r.info[t] & CABAC_TU_INFO_LAST_MASK);
+        const ChannelType ch = it.chroma ? CHANNEL_TYPE_CHROMA : CHANNEL_TYPE_LUMA;
+        if (it.notSkip && it.height >= 4 && it.width >= 4) {
+          const int maxLfnstPos = ((it.height == 4 && it.width == 4) || (it.height == 8 && it.width == 8)) ? 7 : 15;
+          cu->violatesLfnstConstrained[ch] |= last > maxLfnstPos;
+          cu->lfnstLastScanPos |= last >= (it.chroma ? LFNST_LAST_SIG_CHROMA : LFNST_LAST_SIG_LUMA);
+        }
+        if (!it.chroma && it.notSkip) cu->mtsLastScanPos |= last >= 1;
+        if (!it.chroma && (r.info[t] & CABAC_TU_INFO_MTS_VIOLATION)) cu->violatesMtsCoeffConstraint = true;
+      }
+    }
+    m_items.clear();
+  }
+
+private:
+  struct Item {
+    std::vector<int32_t> coeff;
+    unsigned width = 0, height = 0;
+    bool chroma = false, depQuant = false, signHiding = false, tsAllowed = false, notSkip = true;
+    unsigned tsFlag = 0;
+    int maxLog2 = 15;
+    Common::CUCtx *cuCtx = nullptr;
+  };
+  HipBatch &m_batch;
+  EntropyCoding::BinEncIf &m_enc;
+  std::vector<Item> m_items;
 };
 
 }  // namespace EntropyCodingAMD

@@ -52,6 +52,7 @@
 #include "cabac_writer.hpp"
 #undef private
 #undef protected
+#include "ref_rig.hpp"
 #include "arith_codec.hpp"
 #include "bit_stream.hpp"
 #include "contexts.hpp"
@@ -422,25 +423,6 @@ struct RecordingEncoder : public BinEncoder_Std {  // encodeRemAbsEP stays the r
   void encodeBinTrm(unsigned bin) override { rec.push_back(uint16_t((bin & 1u) << 15 | 0x1ff)); }
 };
 
-template <class T> T *zeroed() { return reinterpret_cast<T *>(calloc(1, sizeof(T))); }  // never destroyed
-
-struct ResidualRig {
-  SPS *sps = zeroed<SPS>();
-  Slice *slice = zeroed<Slice>();
-  CodingStructure *cs = zeroed<CodingStructure>();
-  CodingUnit *cu = zeroed<CodingUnit>();
-  ResidualRig() {
-    static bool rom = false;
-    if (!rom) { initROM(); rom = true; }
-    sps->m_bitDepths.recon[0] = sps->m_bitDepths.recon[1] = 10;
-    sps->m_log2MaxTbSize = 6;
-    slice->m_pcSPS = sps;
-    cs->sps = std::shared_ptr<const SPS>(sps, [](const SPS *) {});
-    cs->slice = std::shared_ptr<Slice>(slice, [](Slice *) {});
-    cu->cs = cs;
-    cu->slice = slice;
-  }
-};
 }  // namespace
 extern "C" {
 
@@ -452,26 +434,10 @@ long ref_residual_records(int width, int height, int comp, int flags, const int3
                           int32_t *info) {
   try {
     static ResidualRig rig;
-    rig.slice->m_depQuantEnabledFlag = flags & 1;
-    rig.slice->m_signDataHidingEnabledFlag = (flags >> 1) & 1;
-    rig.sps->m_transformSkipEnabledFlag = (flags >> 2) & 1;
-    rig.sps->m_log2MaxTransformSkipBlockSize = 5;
-    const int depth = (flags >> 8) & 0xff;
-    rig.sps->m_spsRangeExtension.m_extendedPrecisionProcessingFlag = depth != 0;
-    rig.sps->m_bitDepths.recon[0] = rig.sps->m_bitDepths.recon[1] = depth ? depth : 10;
+    std::vector<TCoeff> buf;
     TransformUnit tu;
-    tu.initData();
-    tu.chromaFormat = CHROMA_420;
+    rig.make_tu(tu, buf, width, height, comp, flags, coeff);
     const ComponentID cid = ComponentID(comp);
-    for (int c = 0; c < 3; c++)
-      tu.blocks.push_back(CompArea(ComponentID(c), CHROMA_420, 0, 0, c == comp ? width : 0, c == comp ? height : 0));
-    tu.cu = rig.cu;
-    tu.cs = rig.cs;
-    tu.chType = toChannelType(cid);
-    std::vector<TCoeff> buf(coeff, coeff + (size_t)width * height);
-    for (auto &p : tu.m_coeffs) p = nullptr;
-    tu.m_coeffs[comp] = buf.data();
-    tu.cbf[comp] = 1;
     RecordingEncoder enc;
     CABACWriter w(enc);
     CUCtx cuCtx(0);

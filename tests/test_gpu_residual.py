@@ -186,3 +186,30 @@ def test_blocks_to_bytes_through_the_device_encoder(hip):
         want, nbits = orc.encode_records(want_rec, 32, 2, 3)
         o = int(desc["byte_offset"][s])
         assert int(res["n_bits"][s]) == nbits and np.array_equal(out[o:o + len(want)], want), s
+
+
+def test_host_pointer_batch_api(hip):
+    """cabac_hip_residual_batch (host arrays, both passes inside) == the device API == the oracle."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(99)
+    blocks = [H.random_block(rng, w, h, density=0.5, big=0.1) for (w, h) in [(4, 4), (16, 16), (32, 8), (64, 64), (8, 8)] * 6]
+    chromas = [int(x) for x in rng.integers(0, 2, len(blocks))]
+    flags = [int(x) for x in rng.integers(0, 8, len(blocks))]
+    tus, coeff = make_tus(blocks, chromas, flags)
+    rec, off, info = hip.residual_batch(tus, coeff)
+    assert int(off[0]) == 0 and int(off[-1]) == len(rec)
+    for i, c in enumerate(blocks):
+        want, last, mts = orc.residual_records(c, chromas[i], flags[i])
+        assert np.array_equal(rec[int(off[i]): int(off[i + 1])], want), i
+        assert int(info[i]) == (last | (H.TU_INFO_MTS_VIOLATION if mts else 0))
+    # an all-zero block: flagged, status CABAC_HIP_ERR_SUBSTREAM, the other blocks still coded
+    tus2, coeff2 = make_tus([blocks[0], np.zeros((4, 4), np.int32), blocks[1]], [0, 0, 1], [0, 0, 0])
+    with pytest.raises(capi.CabacHipError):
+        hip.residual_batch(tus2, coeff2)
+    rec2, off2, info2 = hip.residual_batch(tus2, coeff2, check=False)
+    assert int(info2[1]) == H.TU_INFO_EMPTY and int(off2[2]) == int(off2[1])
+    assert np.array_equal(rec2[int(off2[2]): int(off2[3])], orc.residual_records(blocks[1], 1, 0)[0])
+    # coefficients outside the buffer are refused before anything is launched
+    tus3 = tus2.copy(); tus3[2]["coeff_offset"] = len(coeff2)
+    with pytest.raises(capi.CabacHipError):
+        hip.residual_batch(tus3, coeff2)

@@ -33,6 +33,10 @@ def adp():
     L.adapter_estimate.restype = ctypes.c_long
     L.adapter_estimate.argtypes = [ctypes.c_int, H.u32p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int),
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.adapter_residual.restype = ctypes.c_long
+    L.adapter_residual.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, H.u8p, ctypes.c_long,
+                                   ctypes.POINTER(ctypes.c_int32)]
     L.adapter_record.restype = ctypes.c_long
     L.adapter_record.argtypes = [H.u32p, ctypes.c_long, H.u16p, ctypes.c_long, H.u32p]
     return L
@@ -90,3 +94,50 @@ def test_reference_cabacwriter_on_gpu_estimator_matches_bitestimator_std(adp, se
         assert rc == 0, adp.adapter_last_error()
         res.append(costs)
     assert np.array_equal(res[0], res[1])
+
+
+def _residual(adp, which, blocks, comps, rig_flags, qp=32):
+    wh = np.array([[c.shape[1], c.shape[0]] for c in blocks], np.int32).ravel()
+    comp = np.array(comps, np.int32)
+    coeff = np.concatenate([c.ravel() for c in blocks]).astype(np.int32)
+    out = np.zeros(64 + 8 * len(coeff), np.uint8)
+    cu = np.zeros(8, np.int32)
+    ip = ctypes.POINTER(ctypes.c_int)
+    n = adp.adapter_residual(which, len(blocks), wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), rig_flags,
+                             coeff.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), qp, H._ptr(out, H.u8p), len(out),
+                             cu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    assert n >= 0, adp.adapter_last_error()
+    return out[:n].copy(), cu[:4].copy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig_flags", [0, 1, 2, 3, 7])
+def test_residual_coding_through_the_gpu_binariser_matches_reference_writer(adp, rig_flags):
+    """The reference's CABACWriter::residual_coding on its BinEncoder_Std against ResidualCoderHipRef (GPU binariser
+    feeding the same BinEncoder_Std) over the reference's own TransformUnit objects: same bytes, same CUCtx."""
+    rng = np.random.default_rng(0x5E5 + rig_flags)
+    sizes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 16), (32, 8), (2, 8), (64, 16)]
+    blocks, comps = [], []
+    for k in range(40):
+        w, h = sizes[k % len(sizes)]
+        comp = int(rng.integers(0, 3))
+        blocks.append(H.random_block(rng, w, h, density=[0.1, 0.4, 0.9][k % 3], big=[0.0, 0.1, 0.3][k % 3],
+                                     huge=0.02 if k % 7 == 6 else 0.0, last_frac=[1.0, 0.4][k % 2]))
+        comps.append(comp)
+    want, cu_want = _residual(adp, 0, blocks, comps, rig_flags)
+    one, cu_one = _residual(adp, 1, blocks, comps, rig_flags)          # block by block
+    many, cu_many = _residual(adp, 2, blocks, comps, rig_flags)        # queued, one launch
+    assert np.array_equal(one, want) and np.array_equal(cu_one, cu_want)
+    assert np.array_equal(many, want) and np.array_equal(cu_many, cu_want)
+
+
+@pytest.mark.gpu
+def test_residual_adapter_empty_block_throws_like_the_reference(adp):
+    z = [np.zeros((8, 8), np.int32)]
+    for which in (0, 1):
+        wh = np.array([8, 8], np.int32); comp = np.array([0], np.int32); cu = np.zeros(8, np.int32); out = np.zeros(64, np.uint8)
+        ip = ctypes.POINTER(ctypes.c_int)
+        n = adp.adapter_residual(which, 1, wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), 0,
+                                 z[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, H._ptr(out, H.u8p), len(out),
+                                 cu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        assert n == -1 and b"empty TU" in adp.adapter_last_error()
