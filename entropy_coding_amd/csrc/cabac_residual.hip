@@ -323,8 +323,11 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     // template of the position (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176): five
     // neighbours to the right and below, absent ones count as zero.  Loads are unconditional from clamped
     // addresses (no exec juggling); an absent neighbour is zeroed afterwards.
+    // The count-only pass needs the template only for escape codes: a level of 4 or more, or a position the
+    // budget (at most 64 context bins go per group) may no longer reach.
     int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
-    if (act) {
+    const bool want_tmpl = kWrite || __ballot(act && (a >= 4u || budget < 68)) != 0ull;
+    if (want_tmpl && act) {
       const bool x1 = x + 1u < w, x2 = x + 2u < w, y1 = y + 1u < h, y2 = y + 2u < h;
       const uint32_t dx1 = x1 ? 1u : 0u, dx2 = x2 ? 2u : 0u, dy1 = y1 ? w : 0u, dy2 = y2 ? 2u * w : 0u;
       const int32_t v0 = p[dx1], v1 = p[dx2], v2 = p[dy1 + dx1], v3 = p[dy1], v4 = p[dy2];
@@ -452,18 +455,20 @@ size_t residual_scratch_bytes(uint32_t n_tu) {
 
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
-                           void *scratch) {
+                           void *scratch, bool reuse_order) {
   if (n_tu == 0) return hipSuccess;
   // blocks ordered by group count: [counts | cursors | permutation, 0xFFFFFFFF where a class is padded to 16 rows]
   uint32_t *s32 = static_cast<uint32_t *>(scratch);
   const uint32_t rows = n_tu + kClasses * kRowsPerBlock;  // upper bound of the padded list
-  hipError_t e = hipMemsetAsync(s32, 0, sizeof(uint32_t) * kScratchHeader, st);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
-  if (e != hipSuccess) return e;
-  const uint32_t g = (n_tu + 255u) / 256u;
-  hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
-  hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
+  if (!reuse_order) {  // any complete permutation of the n_tu blocks is correct; this one balances the waves
+    hipError_t e = hipMemsetAsync(s32, 0, sizeof(uint32_t) * kScratchHeader, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
+    if (e != hipSuccess) return e;
+    const uint32_t g = (n_tu + 255u) / 256u;
+    hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
+    hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
+  }
   const dim3 grid(rows / kRowsPerBlock);
   if (records)
     hipLaunchKernelGGL(residual_kernel<true>, grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info, records,
