@@ -219,27 +219,29 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   const uint8_t *grid = c_diag.grid[lwg][lhg];
   const bool lane_in_cg = l < cg_size;
 
-  // ---- sweep 1: the last significant position, searched from the end of the scan ----------------------
+  // ---- sweep 1: which groups hold a coefficient, and the last significant position ----------------------
   int last = -1;
+  uint64_t coded = 0;    // by scan index of the group
+  uint64_t sig_map = 0;  // by raster position in the group grid: bit gy * wg + gx
   {
-    int cg = (int)n_cg - 1;  // row-uniform; the rows of a wave normally share n_cg (class order)
-    int top = cg;
+    int top = (int)n_cg - 1;  // the rows of a wave normally share n_cg (class order)
     top = max(top, __shfl_xor(top, 16));
     top = max(top, __shfl_xor(top, 32));
     top = __builtin_amdgcn_readfirstlane(top);
     for (int k = top; k >= 0; k--) {
-      const bool searching = last < 0 && k < (int)n_cg;
-      if (__ballot(searching) == 0ull) break;
+      const bool on = k < (int)n_cg;
       int32_t c = 0;
-      if (searching && lane_in_cg) {
-        const uint32_t gpos = grid[k];
-        c = coeff[((((gpos >> 4) << cgh_l2) + iy) << lw) + ((gpos & 15u) << cgw_l2) + ix];
-      }
+      uint32_t gpos = 0;
+      if (on) gpos = grid[k];
+      if (on && lane_in_cg) c = coeff[((((gpos >> 4) << cgh_l2) + iy) << lw) + ((gpos & 15u) << cgw_l2) + ix];
       const uint32_t nz = row_bits(c != 0, row_shift);
-      if (searching && nz) last = (int)(((uint32_t)k << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
+      if (nz) {
+        if (last < 0) last = (int)(((uint32_t)k << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
+        coded |= 1ull << k;
+        sig_map |= 1ull << ((gpos >> 4) * wg + (gpos & 15u));
+      }
     }
   }
-  uint64_t sig_map = 0;  // bit gy * wg + gx, filled in as sweep 2 meets the groups (right and below come first)
   const bool empty = live && last < 0;
   live = live && !empty;
 
@@ -278,16 +280,45 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   int budget = (int)((we * he * 28u) >> 4);              // cabac_writer.cpp:2485-2489
   uint32_t state = 0;
   const int last_cg = live ? (last >> cg_l2) : -1;
-  int top_cg = last_cg;
-  top_cg = max(top_cg, __shfl_xor(top_cg, 16));
-  top_cg = max(top_cg, __shfl_xor(top_cg, 32));
-  top_cg = __builtin_amdgcn_readfirstlane(top_cg);
+  // Only groups that hold a coefficient (and group 0) are walked; the empty ones in between cost one group flag
+  // each, written sixteen at a time.  `todo` = the groups this row still has to walk, by scan index.
+  uint64_t todo = live ? ((coded | 1ull) & ((2ull << last_cg) - 1ull)) : 0ull;
+  int prev_cg = last_cg + 1;
 
-  for (int cg = top_cg; cg >= 0; cg--) {
-    const bool row_on = cg <= last_cg;  // this row still has groups to code
+  while (__ballot(todo != 0ull) != 0ull) {
+    const bool row_on = todo != 0ull;
+    const int cg = row_on ? 63 - __builtin_clzll(todo) : 0;
+    todo &= ~(1ull << cg);
+    // coded_sub_block_flag (cabac_writer.cpp:2733-2743) of the empty groups passed over, then of this group
+    const uint32_t gap = row_on ? (uint32_t)(prev_cg - 1 - cg) : 0u;
+    if (kWrite) {
+      for (uint32_t base = 0; __ballot(base < gap) != 0ull; base += 16u) {
+        const uint32_t j = base + l;
+        if (j < gap) {
+          const uint32_t sp = grid[prev_cg - 1 - (int)j];
+          const uint32_t sx_ = sp & 15u, sy_ = sp >> 4, sb = sy_ * wg + sx_;
+          const uint32_t right = sx_ + 1u < wg ? (uint32_t)(sig_map >> (sb + 1u)) & 1u : 0u;
+          const uint32_t below = sy_ + 1u < hg ? (uint32_t)(sig_map >> (sb + wg)) & 1u : 0u;
+          out[off + j] = (uint16_t)(CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below));
+        }
+      }
+    }
+    off += gap;
+    prev_cg = row_on ? cg : prev_cg;
     const uint32_t gpos = row_on ? grid[cg] : 0u;
     const uint32_t gx = gpos & 15u, gy = gpos >> 4;
     const uint32_t gbit = gy * wg + gx;
+    const bool coded_group = (coded >> cg) & 1ull;
+    if (row_on && cg != last_cg && cg != 0) {
+      if (kWrite && l == 0u) {
+        const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
+        const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
+        out[off] = (uint16_t)(CABAC_REC_BIN | (CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)));
+      }
+      off += 1u;
+    }
+    const bool walk = row_on;  // residual_coding_subblock goes past its early return for these groups only
+    if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
     const int lo = cg << cg_l2;
     const int first = cg == last_cg ? last : lo + (int)cg_size - 1;
     const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
@@ -303,22 +334,7 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     const bool nzero = c != 0;
     const uint32_t m_nz = row_bits(nzero, row_shift);
 
-    // coded_sub_block_flag (cabac_writer.cpp:2733-2743); the group's neighbours to the right and below were met earlier
-    const bool coded_group = m_nz != 0u;
-    if (row_on && coded_group) sig_map |= 1ull << gbit;
-    const bool has_flag = row_on && cg != last_cg && cg != 0;
-    if (has_flag) {
-      if (kWrite && l == 0u) {
-        const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
-        const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
-        out[off] = (uint16_t)((coded_group ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)));
-      }
-      off += 1u;
-    }
-    const bool walk = row_on && (coded_group || cg == 0);  // residual_coding_subblock goes past its early return
-    if (walk && chroma == 0u && coded_group && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;
     const bool act = walk && in_range;
-    if (__ballot(walk) == 0ull) continue;  // no row of this wave codes anything here beyond the group flag
 
     // template of the position (sigCtxIdAbs / templateAbsSum, context_modelling.hpp:71-117, :152-176): five
     // neighbours to the right and below, absent ones count as zero.  Loads are unconditional from clamped
