@@ -141,13 +141,51 @@ constexpr uint32_t kClasses = 8;
 // scratch layout (uint32): [0..7] blocks per class, [8..15] scatter cursors, [16..] permutation (padded per class)
 constexpr uint32_t kScratchHeader = 16;
 
+// Pre-pass: each thread looks at kSortItems descriptors and keeps its per-class counts as 4-bit fields of one word
+// (a count is at most 8); counts meet through wave shuffles of 16-bit pairs, then one LDS add per wave and class,
+// one global add per workgroup and class.
+constexpr uint32_t kSortItems = 8;
+constexpr uint32_t kSortSpan = 256u * kSortItems;  // descriptors per workgroup
+
+__device__ __forceinline__ uint32_t class_of(const cabac_tu_desc *tus, uint32_t i) {
+  // one 8-byte load of the descriptor's second half: log2_width, log2_height in its low bytes
+  const uint64_t hi = reinterpret_cast<const uint64_t *>(tus)[2u * (uint64_t)i + 1u];
+  cabac_tu_desc d{};
+  d.log2_width = (uint8_t)hi;
+  d.log2_height = (uint8_t)(hi >> 8);
+  return size_class(d);
+}
+
+// per-thread nibble counts -> four words of two 16-bit counts (classes 2k and 2k+1)
+__device__ __forceinline__ void widen_counts(uint32_t nib, uint32_t out[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = ((nib >> (8 * k)) & 15u) | (((nib >> (8 * k + 4)) & 15u) << 16);
+}
+
 __global__ __launch_bounds__(256) void class_hist(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                                    uint32_t *__restrict__ scratch) {
   __shared__ uint32_t h[kClasses];
   if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n_tu) atomicAdd(&h[size_class(tus[i])], 1u);
+  uint32_t nib = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kSortItems; k++) {
+    const uint32_t i = blockIdx.x * kSortSpan + k * 256u + threadIdx.x;
+    if (i < n_tu) nib += 1u << (4u * class_of(tus, i));
+  }
+  uint32_t c[4];
+  widen_counts(nib, c);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) c[k] += (uint32_t)__shfl_xor((int)c[k], d);
+  if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (c[k] & 0xffffu) atomicAdd(&h[2 * k], c[k] & 0xffffu);
+      if (c[k] >> 16) atomicAdd(&h[2 * k + 1], c[k] >> 16);
+    }
+  }
   __syncthreads();
   if (threadIdx.x < kClasses && h[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], h[threadIdx.x]);
 }
@@ -160,20 +198,64 @@ __device__ __forceinline__ uint32_t class_base(const uint32_t *scratch, uint32_t
 
 __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                                       uint32_t *__restrict__ scratch) {
-  __shared__ uint32_t h[kClasses], start[kClasses];
-  if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  uint32_t cls = 0, rank = 0;
-  if (i < n_tu) {
-    cls = size_class(tus[i]);
-    rank = atomicAdd(&h[cls], 1u);
+  __shared__ uint32_t wave_cnt[4][kClasses], start[kClasses];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t nib = 0, cls_all = 0;  // classes of this thread's descriptors, 3 bits each (7 = none / rejected)
+#pragma unroll
+  for (uint32_t k = 0; k < kSortItems; k++) {
+    const uint32_t i = blockIdx.x * kSortSpan + k * 256u + threadIdx.x;
+    uint32_t cls = 7u;
+    if (i < n_tu) {
+      cls = class_of(tus, i);
+      nib += 1u << (4u * cls);
+    }
+    cls_all |= cls << (3u * k);
+  }
+  // exclusive prefix of the counts over the lanes of the wave, and the wave totals
+  uint32_t c[4], incl[4];
+  widen_counts(nib, c);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    incl[k] = c[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl[k], d);
+      if ((int)lane >= d) incl[k] += up;
+    }
+  }
+  if (lane == 63u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wave_cnt[wave][2 * k] = incl[k] & 0xffffu;
+      wave_cnt[wave][2 * k + 1] = incl[k] >> 16;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < kClasses)
-    start[threadIdx.x] = class_base(scratch, threadIdx.x) + (h[threadIdx.x] ? atomicAdd(&scratch[kClasses + threadIdx.x], h[threadIdx.x]) : 0u);
+  if (threadIdx.x < kClasses) {
+    const uint32_t total = wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+    start[threadIdx.x] = class_base(scratch, threadIdx.x) + (total ? atomicAdd(&scratch[kClasses + threadIdx.x], total) : 0u);
+  }
   __syncthreads();
-  if (i < n_tu) scratch[kScratchHeader + start[cls] + rank] = i;
+  uint32_t next[kClasses];  // where this thread's next block of each class goes
+#pragma unroll
+  for (uint32_t q = 0; q < kClasses; q++) {
+    uint32_t before = 0;
+    for (uint32_t v = 0; v < wave; v++) before += wave_cnt[v][q];
+    const uint32_t mine = (q & 1u) ? (incl[q >> 1] >> 16) - (c[q >> 1] >> 16) : (incl[q >> 1] & 0xffffu) - (c[q >> 1] & 0xffffu);
+    next[q] = start[q] + before + mine;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kSortItems; k++) {
+    const uint32_t i = blockIdx.x * kSortSpan + k * 256u + threadIdx.x;
+    const uint32_t cls = (cls_all >> (3u * k)) & 7u;
+    if (i < n_tu) {
+      uint32_t slot = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < kClasses; q++)
+        if (q == cls) slot = next[q]++;
+      scratch[kScratchHeader + slot] = i;
+    }
+  }
 }
 
 template <bool kWrite>
@@ -481,7 +563,7 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
     if (e != hipSuccess) return e;
-    const uint32_t g = (n_tu + 255u) / 256u;
+    const uint32_t g = (n_tu + kSortSpan - 1u) / kSortSpan;
     hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
     hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
   }
