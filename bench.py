@@ -146,7 +146,11 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
             "mcoeff_s": round(n_coef / ((p1 + p2) * 1e-3) / 1e6, 1), "mbins_s": round(n_bins / ((p1 + p2) * 1e-3) / 1e6, 1),
             "algorithmic_bytes_per_launch": {"pass1_count": bytes1, "pass2_write": bytes2},
             "achieved_gbps": {"pass1_count": round(bytes1 / (p1 * 1e-3) / 1e9, 2), "pass2_write": round(bytes2 / (p2 * 1e-3) / 1e9, 2)},
-            "frac_of_hbm_peak": round(bytes2 / (p2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "records_match_reference": bool(ok)}
+            "frac_of_hbm_peak": round(bytes2 / (p2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+            # PMC bytes per launch of residual_kernel<false> / <true> (profiles/pmc_traffic.json), the ordering pre-pass apart
+            "traffic": {"pass1_count": measured_traffic("C4", "residual_kernel_count"),
+                        "pass2_write": measured_traffic("C4", "residual_kernel_write")},
+            "records_match_reference": bool(ok)}
 
 
 def main():
