@@ -258,16 +258,18 @@ __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_
   }
 }
 
-template <bool kWrite>
-__global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
-                                                        const int32_t *__restrict__ coeff_all,
-                                                        const uint64_t *__restrict__ rec_offset,
-                                                        uint32_t *__restrict__ n_records,
-                                                        uint32_t *__restrict__ info_out,
-                                                        uint16_t *__restrict__ records,
-                                                        const uint32_t *__restrict__ perm) {
+// kStage: the blocks of this launch (512 or 1024 coded coefficients) are first copied into LDS row by row — every
+// 128-byte line of the block is fetched once and used whole — and all later reads (scan-order walks, templates) go
+// to LDS.  Read straight from memory in scan order such a block costs a line per 16 bytes used, and with every wave
+// of an XCD holding four of them the lines do not survive in L2 between uses (measured: 10 x the block's bytes).
+// Smaller blocks fit a line or two and are read directly.
+template <bool kWrite, bool kStage>
+__device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage, uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
+                                              const int32_t *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
+                                              uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
+                                              uint16_t *__restrict__ records, const uint32_t *__restrict__ perm) {
   const uint32_t lane = threadIdx.x & 63u, l = lane & 15u, row_shift = lane & 48u;
-  const uint32_t tu_idx = perm[blockIdx.x * kRowsPerBlock + (threadIdx.x >> 4)];  // 0xFFFFFFFF: padding
+  const uint32_t tu_idx = perm[wg_index * kRowsPerBlock + (threadIdx.x >> 4)];  // 0xFFFFFFFF: padding
   bool live = tu_idx < n_tu;
 
   // ---- geometry (row-uniform) -------------------------------------------------------------------
@@ -301,6 +303,33 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   const uint8_t *grid = c_diag.grid[lwg][lhg];
   const bool lane_in_cg = l < cg_size;
 
+  const uint32_t lwe = 31u - (uint32_t)__builtin_clz(we);
+  const uint32_t stage_base = (threadIdx.x >> 4) * 1024u;
+  if (kStage) {
+    const uint32_t total = live ? we * he : 0u;  // 512 or 1024 here
+    uint32_t tmax = total;
+    tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, 16));
+    tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, 32));
+    tmax = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tmax), 1024u);
+    for (uint32_t i = l; i < tmax; i += 64u) {
+      int32_t v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+        const uint32_t idx = i + 16u * u;
+        v[u] = idx < total ? coeff[((idx >> lwe) << lw) + (idx & (we - 1u))] : 0;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+        const uint32_t idx = i + 16u * u;
+        if (idx < total) stage[stage_base + idx] = v[u];
+      }
+    }
+  }
+  // coefficient (x, y) of this row's block; within the coded region only
+  auto coef_at = [&](uint32_t x, uint32_t y) -> int32_t {
+    return kStage ? stage[stage_base + (y << lwe) + x] : coeff[(y << lw) + x];
+  };
+
   // ---- sweep 1: which groups hold a coefficient, and the last significant position ----------------------
   int last = -1;
   uint64_t coded = 0;    // by scan index of the group
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
       int32_t c = 0;
       uint32_t gpos = 0;
       if (on) gpos = grid[k];
-      if (on && lane_in_cg) c = coeff[((((gpos >> 4) << cgh_l2) + iy) << lw) + ((gpos & 15u) << cgw_l2) + ix];
+      if (on && lane_in_cg) c = coef_at(((gpos & 15u) << cgw_l2) + ix, ((gpos >> 4) << cgh_l2) + iy);
       const uint32_t nz = row_bits(c != 0, row_shift);
       if (nz) {
         if (last < 0) last = (int)(((uint32_t)k << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
@@ -410,8 +439,7 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
 
     // the coefficient; its template is fetched below, once it is known that somebody codes this group
     int32_t c = 0;
-    const int32_t *p = coeff + (y << lw) + x;
-    if (in_range) c = p[0];
+    if (in_range) c = coef_at(x, y);
     const uint32_t a = (uint32_t)(c < 0 ? -c : c);
     const bool nzero = c != 0;
     const uint32_t m_nz = row_bits(nzero, row_shift);
@@ -426,9 +454,11 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
     const bool want_tmpl = kWrite || __ballot(act && (a >= 4u || budget < 68)) != 0ull;
     if (want_tmpl && act) {
-      const bool x1 = x + 1u < w, x2 = x + 2u < w, y1 = y + 1u < h, y2 = y + 2u < h;
-      const uint32_t dx1 = x1 ? 1u : 0u, dx2 = x2 ? 2u : 0u, dy1 = y1 ? w : 0u, dy2 = y2 ? 2u * w : 0u;
-      const int32_t v0 = p[dx1], v1 = p[dx2], v2 = p[dy1 + dx1], v3 = p[dy1], v4 = p[dy2];
+      // the coded region is the block, or its top-left 32 x 32: what lies outside is zero by construction of the
+      // stream (rom.cpp:218-226) and is not read
+      const bool x1 = x + 1u < we, x2 = x + 2u < we, y1 = y + 1u < he, y2 = y + 2u < he;
+      const uint32_t xa = x + (x1 ? 1u : 0u), xb = x + (x2 ? 2u : 0u), ya = y + (y1 ? 1u : 0u), yb = y + (y2 ? 2u : 0u);
+      const int32_t v0 = coef_at(xa, y), v1 = coef_at(xb, y), v2 = coef_at(xa, ya), v3 = coef_at(x, ya), v4 = coef_at(x, yb);
       auto add = [&](int32_t v, bool present) {
         int a = v < 0 ? -v : v;
         a = present ? a : 0;
@@ -547,6 +577,29 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   }
 }
 
+// The block order starts with the classes 7 (rejected), 6, 5: those rows are the staged launch's, a small grid whose
+// workgroups take them in turn (LDS leaves room for two workgroups per CU anyway); the direct launch has one
+// workgroup per 16 rows and the few that fall into the staged range leave at once.
+template <bool kWrite, bool kStage>
+__global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
+                                                        const int32_t *__restrict__ coeff_all,
+                                                        const uint64_t *__restrict__ rec_offset,
+                                                        uint32_t *__restrict__ n_records,
+                                                        uint32_t *__restrict__ info_out,
+                                                        uint16_t *__restrict__ records,
+                                                        const uint32_t *__restrict__ perm,
+                                                        const uint32_t *__restrict__ class_count) {
+  __shared__ int32_t stage[kStage ? kRowsPerBlock * 1024u : 1u];
+  const uint32_t r = kRowsPerBlock - 1u;
+  const uint32_t big_wgs = (((class_count[7] + r) & ~r) + ((class_count[6] + r) & ~r) + ((class_count[5] + r) & ~r)) / kRowsPerBlock;
+  if (kStage) {
+    for (uint32_t wg = blockIdx.x; wg < big_wgs; wg += gridDim.x)
+      residual_rows<kWrite, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+  } else if (blockIdx.x >= big_wgs) {
+    residual_rows<kWrite, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+  }
+}
+
 size_t residual_scratch_bytes(uint32_t n_tu) {
   return sizeof(uint32_t) * (kScratchHeader + (size_t)n_tu + kClasses * kRowsPerBlock);
 }
@@ -568,12 +621,19 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
     hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
   }
   const dim3 grid(rows / kRowsPerBlock);
-  if (records)
-    hipLaunchKernelGGL(residual_kernel<true>, grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info, records,
-                       s32 + kScratchHeader);
-  else
-    hipLaunchKernelGGL(residual_kernel<false>, grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info, records,
-                       s32 + kScratchHeader);
+  const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u);
+  const uint32_t *order = s32 + kScratchHeader;
+  if (records) {
+    hipLaunchKernelGGL((residual_kernel<true, true>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+    hipLaunchKernelGGL((residual_kernel<true, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+  } else {
+    hipLaunchKernelGGL((residual_kernel<false, true>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+    hipLaunchKernelGGL((residual_kernel<false, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+  }
   return hipGetLastError();
 }
 
