@@ -215,8 +215,9 @@ int cabac_hip_binarize_device(cabac_hip_ctx *ctx, uint32_t n_sub, const uint64_t
  * asks its bin encoder for: ts_flag (:2527-2534), last_sig_coeff (:2639-2720) and, per coefficient group in
  * reverse scan order, residual_coding_subblock (:2722-2872) with the context selection of CoeffCodingContext
  * (context_modelling.hpp:71-244, context_modelling.cpp:7-106) and the scans of rom.cpp:148-260.
- * Regular residual coding only: transform-skip blocks (residual_codingTS), SBT/MTS zero-out and the range
- * extensions (extended Rice derivation, persistent Rice adaptation) are not covered.
+ * Regular residual coding and transform-skip residual coding (residual_codingTS, cabac_writer.cpp:2874-3046, with
+ * BDPCM); SBT/MTS zero-out and the range extensions (extended Rice derivation, persistent Rice adaptation, TSRC Rice)
+ * are not covered.
  * One block = one cabac_tu_desc; coefficients are int32 (the reference's TCoeff), raster, stride = width.
  * For blocks wider/taller than 32 only the top-left 32x32 region is coded (rom.cpp:218-226). */
 typedef struct cabac_tu_desc {
@@ -231,7 +232,10 @@ typedef struct cabac_tu_desc {
 
 #define CABAC_TU_DEP_QUANT 0x1u   /* Slice::getDepQuantEnabledFlag                                   */
 #define CABAC_TU_SIGN_HIDING 0x2u /* Slice::getSignDataHidingEnabledFlag                             */
-#define CABAC_TU_TS_FLAG 0x4u     /* TU::isTSAllowed(tu, compID): transform_skip_flag = 0 is coded   */
+#define CABAC_TU_TS_FLAG 0x4u     /* TU::isTSAllowed(tu, compID): transform_skip_flag is coded (0, or 1 with TRANSFORM_SKIP) */
+#define CABAC_TU_TRANSFORM_SKIP 0x8u /* mtsIdx == MTS_SKIP and TS residual coding enabled: residual_codingTS
+                                      * (cabac_writer.cpp:2874-3046) instead of the regular walk; blocks up to 32 x 32  */
+#define CABAC_TU_BDPCM 0x10u      /* with TRANSFORM_SKIP: cu.bdpcmMode / bdpcmModeChroma != 0                  */
 
 /* d_info[t] (may be NULL): scanPosLast in bits 15..0, what residual_coding records in its CUCtx argument */
 #define CABAC_TU_INFO_LAST_MASK 0xFFFFu
@@ -247,6 +251,12 @@ typedef struct cabac_tu_desc {
 #define CABAC_CTX_LAST_X(ch) ((ch) ? 266u : 246u)
 #define CABAC_CTX_LAST_Y(ch) ((ch) ? 289u : 269u)
 #define CABAC_CTX_TRANSFORM_SKIP_FLAG(ch) (310u + (ch))
+#define CABAC_CTX_TS_SIG_COEFF_GROUP 357u
+#define CABAC_CTX_TS_SIG_FLAG 360u
+#define CABAC_CTX_TS_PAR_FLAG 363u
+#define CABAC_CTX_TS_GTX_FLAG 364u
+#define CABAC_CTX_TS_LRG1_FLAG 369u
+#define CABAC_CTX_TS_RESIDUAL_SIGN 373u
 
 /* Upper bound on the records of one block of n = min(32,w)*min(32,h) coded coefficients:
  * 1 + 2*12 + 8 (ts flag, last position) + per coefficient 4 context bins, a 32-bin escape and a sign,

@@ -1002,6 +1002,89 @@ static unsigned last_min_in_group(unsigned gidx) { /* g_minInGroup, rom.cpp:18-1
   return gidx < 4 ? gidx : (2u + (gidx & 1)) << ((gidx >> 1) - 1);
 }
 
+/* Transform-skip residual coding: CABACWriter::residual_codingTS / residual_coding_subblockTS (cabac_writer.cpp:2874-3046)
+ * with the TS context selection and level mapping of CoeffCodingContext (context_modelling.hpp:268-371).  Groups and
+ * positions in forward scan order; neighbours are the left and the upper sample.  TSRC Rice extension off (rice = 1). */
+static int ts_mod_level(int left, int above, int a, int bdpcm) { /* deriveModCoeff, context_modelling.hpp:344-364 */
+  if (a == 0 || bdpcm) return a;
+  if (left < 0) left = -left;
+  if (above < 0) above = -above;
+  const int pred = left > above ? left : above;
+  return a == pred ? 1 : (a < pred ? a + 1 : a);
+}
+
+static long residual_ts(rec_sink *r, const blk_geom *g, const uint32_t *scan, const int32_t *coeff, int bdpcm,
+                        int max_log2_range) {
+#define SX(p) ((int)(scan[p] & 0xffff))
+#define SY(p) ((int)(scan[p] >> 16))
+#define AT(x, y) (coeff[(y) * g->w + (x)])
+  const int n_cg = (g->w * g->h) >> g->cg_l2, cg_size = 1 << g->cg_l2;
+  uint8_t cg_sig[64];
+  int n_sig = 0;
+  memset(cg_sig, 0, sizeof cg_sig);
+  int budget = (g->w * g->h * 7) >> 2;
+  for (int cg = 0; cg < n_cg; cg++) {
+    const int lo = cg << g->cg_l2, hi = lo + cg_size - 1;
+    const int cgx = SX(lo) >> g->cgw_l2, cgy = SY(lo) >> g->cgh_l2;
+    int sig = 0;
+    for (int p = lo; p <= hi; p++) sig |= AT(SX(p), SY(p)) != 0;
+    if (sig) { cg_sig[cgy * g->wg + cgx] = 1; n_sig++; }
+    if (cg != n_cg - 1 || n_sig - sig != 0) { /* :2933-2942: not (last group and no group before it significant) */
+      const int left = cgx > 0 ? cg_sig[cgy * g->wg + cgx - 1] : 0, above = cgy > 0 ? cg_sig[(cgy - 1) * g->wg + cgx] : 0;
+      rs_put(r, CABAC_CTX_TS_SIG_COEFF_GROUP + (unsigned)(left + above), (unsigned)sig);
+      if (!sig) continue;
+    }
+    int n_nz = 0, last1 = -1, last2 = -1, p;
+    for (p = lo; p <= hi && budget >= 4; p++) { /* pass 1 */
+      const int x = SX(p), y = SY(p), v = AT(x, y);
+      const int left = x > 0 ? AT(x - 1, y) : 0, above = y > 0 ? AT(x, y - 1) : 0;
+      const int n_nb = (left != 0) + (above != 0);
+      if (n_nz || p != hi) {
+        rs_put(r, CABAC_CTX_TS_SIG_FLAG + (unsigned)n_nb, v != 0);
+        budget--;
+      }
+      if (v) {
+        const int sl = (left > 0) - (left < 0), sa = (above > 0) - (above < 0);
+        unsigned sctx = ((sl == 0 && sa == 0) || sl * sa < 0) ? 0u : (sl >= 0 && sa >= 0) ? 1u : 2u;
+        if (bdpcm) sctx += 3;
+        rs_put(r, CABAC_CTX_TS_RESIDUAL_SIGN + sctx, v < 0);
+        const int m = ts_mod_level(left, above, v < 0 ? -v : v, bdpcm);
+        rs_put(r, CABAC_CTX_TS_LRG1_FLAG + (unsigned)(bdpcm ? 3 : n_nb), m > 1);
+        budget -= 2;
+        n_nz++;
+        if (m > 1) {
+          rs_put(r, CABAC_CTX_TS_PAR_FLAG, (unsigned)((m - 2) & 1));
+          budget--;
+        }
+      }
+      last1 = p;
+    }
+    for (p = lo; p <= hi && budget >= 4; p++) { /* pass 2: greater-than-3/5/7/9 flags */
+      const int x = SX(p), y = SY(p), v = AT(x, y);
+      const int m = ts_mod_level(x > 0 ? AT(x - 1, y) : 0, y > 0 ? AT(x, y - 1) : 0, v < 0 ? -v : v, bdpcm);
+      for (int cut = 2; cut <= 8; cut += 2)
+        if (m >= cut) {
+          rs_put(r, CABAC_CTX_TS_GTX_FLAG + (unsigned)(cut >> 1), m >= cut + 2);
+          budget--;
+        }
+      last2 = p;
+    }
+    for (p = lo; p <= hi; p++) { /* pass 3: remainders and the signs of the bypass-coded positions */
+      const int x = SX(p), y = SY(p), v = AT(x, y);
+      const int cut = p <= last2 ? 10 : p <= last1 ? 2 : 0;
+      const int m = ts_mod_level(x > 0 ? AT(x - 1, y) : 0, y > 0 ? AT(x, y - 1) : 0, v < 0 ? -v : v, bdpcm || !cut);
+      if (m >= cut) {
+        rs_rem_abs(r, p <= last1 ? (unsigned)(m - cut) >> 1 : (unsigned)m, 1, 5, max_log2_range);
+        if (m && p > last1) rs_put(r, CABAC_REC_EP, v < 0);
+      }
+    }
+  }
+#undef SX
+#undef SY
+#undef AT
+  return r->n;
+}
+
 /* Returns the number of records (written up to cap), -1 for an all-zero block (the reference throws),
  * -2 for a bad size.  info (may be NULL): scanPosLast | CABAC_TU_INFO_MTS_VIOLATION. */
 long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_log2_range, const int32_t *coeff,
@@ -1030,7 +1113,13 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
   if (last < 0) { free(scan); return -1; }
   uint32_t info_bits = (uint32_t)last;
 
-  if (flags & CABAC_TU_TS_FLAG) rs_put(&r, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma), 0);
+  if (flags & CABAC_TU_TS_FLAG) rs_put(&r, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma), (flags & CABAC_TU_TRANSFORM_SKIP) != 0);
+  if (flags & CABAC_TU_TRANSFORM_SKIP) {
+    const long n_ts = residual_ts(&r, &g, scan, coeff, (flags & CABAC_TU_BDPCM) != 0, max_log2_range);
+    free(scan);
+    if (info) *info = info_bits;
+    return n_ts;
+  }
 
   { /* last significant position, cabac_writer.cpp:2639-2720 */
     const unsigned px = (unsigned)SX(last), py = (unsigned)SY(last);

@@ -28,6 +28,7 @@ struct ResidualRig {
     cu->slice = slice;
   }
   // flags: bit0 dep_quant, bit1 sign_data_hiding, bit2 transform skip enabled in the SPS (max size 32),
+  //        bit4 the block is transform-skip coded (mtsIdx = MTS_SKIP), bit5 BDPCM (cu.bdpcmMode / bdpcmModeChroma),
   //        bits 8..15: if non-zero, extended_precision_processing with this bit depth.  comp: 0 Y, 1 Cb, 2 Cr.
   void make_tu(Common::TransformUnit &tu, std::vector<Common::TCoeff> &buf, int width, int height, int comp, int flags,
                const int32_t *coeff) {
@@ -51,6 +52,9 @@ struct ResidualRig {
     for (auto &p : tu.m_coeffs) p = nullptr;
     tu.m_coeffs[comp] = buf.data();
     tu.cbf[comp] = 1;
+    tu.mtsIdx[comp] = (flags & 0x10) ? MTS_SKIP : MTS_DCT2_DCT2;
+    cu->bdpcmMode = (flags & 0x20) ? 1 : 0;
+    cu->bdpcmModeChroma = (flags & 0x20) ? 1 : 0;
   }
 };
 }  // namespace

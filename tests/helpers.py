@@ -40,7 +40,7 @@ RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
 # cabac_tu_desc and friends (include/cabac_hip.h)
 TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_height", "u1"), ("channel", "u1"),
                      ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
-TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG = 1, 2, 4
+TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM = 1, 2, 4, 8, 16
 TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
 
 
@@ -233,7 +233,8 @@ class CodecLib:
         info = np.zeros(8, np.int32)
         assert max_log2_range == 15 or 17 <= max_log2_range <= 20   # min(20, bit depth + 6) under extended precision
         depth = 0 if max_log2_range == 15 else max_log2_range - 6
-        n = f(w, h, 1 if chroma else 0, (flags & 7) | (8 if with_cuctx else 0) | depth << 8, _ptr(coeff, i32p), _ptr(out, u16p), cap,
+        rig = (flags & 7) | (8 if with_cuctx else 0) | (0x10 if flags & TU_TRANSFORM_SKIP else 0) | (0x20 if flags & TU_BDPCM else 0)
+        n = f(w, h, 1 if chroma else 0, rig | depth << 8, _ptr(coeff, i32p), _ptr(out, u16p), cap,
               _ptr(info, i32p))
         if n == -1:
             self.lib.ref_last_error.restype = ctypes.c_char_p

@@ -87,6 +87,48 @@ def test_extended_precision_dynamic_range_matches_reference():
                 assert np.array_equal(got, want), (rng_bits, w, h, k)
 
 
+def _ts_block(rng, w, h, kind):
+    """Transform-skip blocks are spatial residuals: no fall-off towards high frequencies, runs of equal values."""
+    if kind == 0:
+        c = (rng.random((h, w)) < 0.3) * rng.integers(-4, 5, (h, w))
+    elif kind == 1:
+        c = rng.integers(-40, 41, (h, w))
+    elif kind == 2:
+        c = np.repeat(rng.integers(-3, 4, (h, 1)), w, 1) * (rng.random((h, w)) < 0.8)
+    else:
+        c = (rng.random((h, w)) < 0.05) * rng.integers(-3000, 3000, (h, w))
+    c = c.astype(np.int32)
+    if not c.any():
+        c[rng.integers(0, h), rng.integers(0, w)] = 1
+    return c
+
+
+@needs_ref
+def test_transform_skip_blocks_match_reference():
+    """residual_codingTS (cabac_writer.cpp:2874-3046): mtsIdx == MTS_SKIP, with and without BDPCM, ts_flag coded or not."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0x75)
+    for w in (1, 2, 4, 8, 16, 32):
+        for h in (1, 2, 4, 8, 16, 32):
+            for k in range(8):
+                c = _ts_block(rng, w, h, k % 4)
+                for chroma in (0, 1):
+                    for extra in (H.TU_TS_FLAG, H.TU_BDPCM, 0):          # the reference codes ts_flag iff allowed: never with BDPCM
+                        flags = H.TU_TRANSFORM_SKIP | extra | (k & 3)
+                        want, _ = ref.residual_records(c, chroma, flags)
+                        got, _, _ = orc.residual_records(c, chroma, flags)
+                        assert np.array_equal(got, want), (w, h, k, chroma, flags)
+    # budget exhaustion (7/4 context bins per sample) and 32-bin escapes
+    for w, h in [(4, 4), (32, 32), (8, 16)]:
+        for v in (1, -7, 2000, -32768):
+            c = np.full((h, w), v, np.int32)
+            c[::2, 1::2] = -v if v != -32768 else 32767
+            for flags in (H.TU_TRANSFORM_SKIP | H.TU_TS_FLAG, H.TU_TRANSFORM_SKIP | H.TU_BDPCM):
+                want, _ = ref.residual_records(c, 0, flags)
+                got, _, _ = orc.residual_records(c, 0, flags)
+                assert np.array_equal(got, want), (w, h, v, flags)
+
+
 def test_golden_blocks():
     orc = H.load_oracle()
     g = np.load(os.path.join(H.GOLDEN, "residual.npz"))
