@@ -79,6 +79,21 @@ __device__ __forceinline__ uint32_t row_shl(uint32_t v) {  // lane l <- lane l +
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 | N, 0xf, 0xf, true);
 }
 
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v) {  // lane l <- lane l - N of the same row, 0 outside
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 | N, 0xf, 0xf, true);
+}
+
+// sum of v over the lanes below this one in its row (forward scan order: transform-skip blocks)
+__device__ __forceinline__ uint32_t row_sum_below(uint32_t v) {
+  uint32_t s = v;
+  s += row_shr<1>(s);
+  s += row_shr<2>(s);
+  s += row_shr<4>(s);
+  s += row_shr<8>(s);
+  return s - v;
+}
+
 // sum of v over the lanes above this one in its row (the positions coded before it)
 __device__ __forceinline__ uint32_t row_sum_above(uint32_t v) {
   uint32_t s = v;
@@ -284,7 +299,8 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     max_log2 = d.max_log2_tr_range ? d.max_log2_tr_range : 15u;
     coeff = coeff_all + d.coeff_offset;
   }
-  const bool bad = live && (lw > 6u || lh > 6u || chroma > 1u || max_log2 > 20u);
+  const bool bad = live && (lw > 6u || lh > 6u || chroma > 1u || max_log2 > 20u ||
+                            ((flags & CABAC_TU_TRANSFORM_SKIP) && (lw > 5u || lh > 5u)));  // TS blocks are at most 32 x 32
   if (bad) lw = lh = chroma = 0;
   live = live && !bad;
   const uint32_t w = 1u << lw, h = 1u << lh;
@@ -361,11 +377,12 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   uint32_t info = live ? (uint32_t)last : (bad ? CABAC_TU_INFO_BAD_DESC : empty ? CABAC_TU_INFO_EMPTY : 0u);
 
   // ---- ts_flag and the last position ------------------------------------------------------------------
-  if (live) {
-    if (flags & CABAC_TU_TS_FLAG) {
-      if (kWrite && l == 0u) out[0] = (uint16_t)CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma);
-      off = 1;
-    }
+  const bool is_ts = live && (flags & CABAC_TU_TRANSFORM_SKIP);
+  if (live && (flags & CABAC_TU_TS_FLAG)) {
+    if (kWrite && l == 0u) out[0] = (uint16_t)((is_ts ? CABAC_REC_BIN : 0u) | CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma));
+    off = 1;
+  }
+  if (live && !is_ts) {
     const uint32_t lcg = (uint32_t)last >> cg_l2;
     const uint32_t lgp = grid[lcg];
     const uint32_t lin = c_diag.in_cg[cgw_l2][cgh_l2][(uint32_t)last & (cg_size - 1u)];
@@ -387,13 +404,13 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   }
 
   // ---- sweep 2: the coefficient groups in coding order ----------------------------------------------
-  const bool dq = live && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
+  const bool dq = live && !is_ts && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
   int budget = (int)((we * he * 28u) >> 4);              // cabac_writer.cpp:2485-2489
   uint32_t state = 0;
   const int last_cg = live ? (last >> cg_l2) : -1;
   // Only groups that hold a coefficient (and group 0) are walked; the empty ones in between cost one group flag
   // each, written sixteen at a time.  `todo` = the groups this row still has to walk, by scan index.
-  uint64_t todo = live ? ((coded | 1ull) & ((2ull << last_cg) - 1ull)) : 0ull;
+  uint64_t todo = (live && !is_ts) ? ((coded | 1ull) & ((2ull << last_cg) - 1ull)) : 0ull;
   int prev_cg = last_cg + 1;
 
   while (__ballot(todo != 0ull) != 0ull) {
@@ -568,6 +585,118 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     if (walk) {
       off += n_ctx_bins + total23 + n_signs;
       budget -= (int)n_ctx_bins;
+    }
+  }
+
+  // ---- transform-skip blocks: residual_codingTS / residual_coding_subblockTS (cabac_writer.cpp:2874-3046) ----------
+  // Forward scan order, neighbours are the left and the upper sample, signs are context coded in the first pass, the
+  // level is mapped through its neighbours (deriveModCoeff, context_modelling.hpp:344-364).  Budget: 7/4 context bins
+  // per sample for the block, checked before every position of pass 1 (sig, sign, >1, parity) and of pass 2 (up to
+  // four greater-than flags): both are prefix sums over the lanes below.
+  if (__ballot(is_ts) != 0ull) {
+    const bool bdpcm = (flags & CABAC_TU_BDPCM) != 0u;
+    int tbudget = (int)((w * h * 7u) >> 2);
+    uint32_t top = is_ts ? n_cg : 0u;
+    top = max(top, (uint32_t)__shfl_xor((int)top, 16));
+    top = max(top, (uint32_t)__shfl_xor((int)top, 32));
+    top = (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
+    const uint32_t below_mask = (1u << l) - 1u;
+    for (uint32_t cg = 0; cg < top; cg++) {
+      const bool row_on = is_ts && cg < n_cg;
+      const uint32_t gpos = row_on ? grid[cg] : 0u;
+      const uint32_t gx = gpos & 15u, gy = gpos >> 4, gbit = gy * wg + gx;
+      const bool coded_group = (coded >> cg) & 1ull;
+      const bool others = (coded & ((1ull << cg) - 1ull)) != 0ull;  // a significant group before this one
+      const bool has_flag = row_on && (cg != n_cg - 1u || others);  // cabac_writer.cpp:2933
+      if (has_flag) {
+        if (kWrite && l == 0u) {
+          const uint32_t left = gx > 0u ? (uint32_t)(sig_map >> (gbit - 1u)) & 1u : 0u;
+          const uint32_t above = gy > 0u ? (uint32_t)(sig_map >> (gbit - wg)) & 1u : 0u;
+          out[off] = (uint16_t)((coded_group ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_SIG_COEFF_GROUP + left + above));
+        }
+        off += 1u;
+      }
+      const bool walk = row_on && (coded_group || !has_flag);
+      if (__ballot(walk) == 0ull) continue;
+      const bool act = walk && lane_in_cg;
+      const uint32_t x = (gx << cgw_l2) + ix, y = (gy << cgh_l2) + iy;
+      int32_t c = 0, vl = 0, va = 0;
+      if (act) {
+        c = coef_at(x, y);
+        vl = coef_at(x > 0u ? x - 1u : x, y);
+        va = coef_at(x, y > 0u ? y - 1u : y);
+        vl = x > 0u ? vl : 0;
+        va = y > 0u ? va : 0;
+      }
+      const uint32_t a = (uint32_t)(c < 0 ? -c : c);
+      const bool nzero = c != 0;
+      const uint32_t n_nb = (vl != 0 ? 1u : 0u) + (va != 0 ? 1u : 0u);
+      uint32_t mod = a;  // deriveModCoeff
+      if (!bdpcm && a != 0u) {
+        const uint32_t pred = max((uint32_t)(vl < 0 ? -vl : vl), (uint32_t)(va < 0 ? -va : va));
+        mod = a == pred ? 1u : (a < pred ? a + 1u : a);
+      }
+      // pass 1
+      const uint32_t m_nz = row_bits(nzero, row_shift);
+      const bool sig_coded = act && !(l == cg_size - 1u && (m_nz & below_mask) == 0u);
+      const uint32_t m_sig = row_bits(sig_coded, row_shift);
+      const uint32_t m_g1 = row_bits(nzero && mod > 1u, row_shift);
+      const uint32_t spent1 = (uint32_t)__builtin_popcount(m_sig & below_mask) + 2u * (uint32_t)__builtin_popcount(m_nz & below_mask) +
+                              (uint32_t)__builtin_popcount(m_g1 & below_mask);
+      const bool pass1 = act && (tbudget - (int)spent1 >= 4);
+      const uint32_t m_p1 = row_bits(pass1, row_shift);
+      const uint32_t n1 = (uint32_t)__builtin_popcount(m_sig & m_p1) + 2u * (uint32_t)__builtin_popcount(m_nz & m_p1) +
+                          (uint32_t)__builtin_popcount(m_g1 & m_p1);
+      const int last1 = m_p1 ? 31 - __builtin_clz(m_p1) : -1;
+      // pass 2
+      const uint32_t cost2 = mod >= 2u ? min(4u, mod >> 1) : 0u;
+      const uint32_t m_c0 = row_bits(act && (cost2 & 1u), row_shift), m_c1 = row_bits(act && (cost2 & 2u), row_shift),
+                     m_c2 = row_bits(act && (cost2 & 4u), row_shift);
+      const uint32_t spent2 = (uint32_t)__builtin_popcount(m_c0 & below_mask) + 2u * (uint32_t)__builtin_popcount(m_c1 & below_mask) +
+                              4u * (uint32_t)__builtin_popcount(m_c2 & below_mask);
+      const bool pass2 = act && (tbudget - (int)n1 - (int)spent2 >= 4);
+      const uint32_t m_p2 = row_bits(pass2, row_shift);
+      const uint32_t n2 = (uint32_t)__builtin_popcount(m_c0 & m_p2) + 2u * (uint32_t)__builtin_popcount(m_c1 & m_p2) +
+                          4u * (uint32_t)__builtin_popcount(m_c2 & m_p2);
+      const int last2 = m_p2 ? 31 - __builtin_clz(m_p2) : -1;
+      // pass 3
+      const uint32_t cut = (int)l <= last2 ? 10u : ((int)l <= last1 ? 2u : 0u);
+      const uint32_t lvl = cut ? mod : a;
+      const bool has_rem = act && lvl >= cut;
+      const bool ep_sign = has_rem && lvl != 0u && (int)l > last1;
+      EpCode ep = {0, 0, 0, 0};
+      if (has_rem) ep = rem_abs_code((int)l <= last1 ? (lvl - cut) >> 1 : lvl, 1u, max_log2);
+      const uint32_t n3 = ep.len1 + ep.len2 + (ep_sign ? 1u : 0u);
+      const uint32_t before3 = row_sum_below(n3);
+      const uint32_t total3 = (uint32_t)__shfl((int)(before3 + n3), (int)(lane | 15u));
+      if (kWrite && act) {
+        if (pass1) {
+          uint16_t *o1 = out + off + spent1;
+          if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_SIG_FLAG + n_nb));
+          if (nzero) {
+            const int sl = (vl > 0) - (vl < 0), sa = (va > 0) - (va < 0);  // signCtxIdAbsTS, context_modelling.hpp:293-317
+            uint32_t sctx = ((sl == 0 && sa == 0) || sl * sa < 0) ? 0u : (sl >= 0 && sa >= 0) ? 1u : 2u;
+            sctx += bdpcm ? 3u : 0u;
+            *o1++ = (uint16_t)((c < 0 ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_RESIDUAL_SIGN + sctx));
+            *o1++ = (uint16_t)((mod > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_LRG1_FLAG + (bdpcm ? 3u : n_nb)));
+            if (mod > 1u) *o1 = (uint16_t)((((mod - 2u) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_CTX_TS_PAR_FLAG);
+          }
+        }
+        if (pass2) {
+          uint16_t *o2 = out + off + n1 + spent2;
+          for (uint32_t k = 1; k <= cost2; k++)  // greater-than-(2k+1) flags, contexts TsGtxFlag(1..4)
+            o2[k - 1u] = (uint16_t)((mod >= 2u * k + 2u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_GTX_FLAG + k));
+        }
+        uint16_t *o3 = out + off + n1 + n2 + before3;
+        for (uint32_t j = 0; j < ep.len1; j++) o3[j] = (uint16_t)((((ep.code1 >> (ep.len1 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+        o3 += ep.len1;
+        for (uint32_t j = 0; j < ep.len2; j++) o3[j] = (uint16_t)((((ep.code2 >> (ep.len2 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+        if (ep_sign) o3[ep.len2] = (uint16_t)((c < 0 ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+      }
+      if (walk) {
+        off += n1 + n2 + total3;
+        tbudget -= (int)(n1 + n2);
+      }
     }
   }
 

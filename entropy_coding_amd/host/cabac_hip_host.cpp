@@ -205,7 +205,8 @@ HipBatch::ResidualResult HipBatch::residual(const std::vector<ResidualBlock> &bl
     tus[t].log2_height = uint8_t(lh);
     tus[t].channel = b.chroma ? 1 : 0;
     tus[t].flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
-                           (b.tsFlag ? CABAC_TU_TS_FLAG : 0u));
+                           (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
+                           (b.transformSkip && b.bdpcm ? CABAC_TU_BDPCM : 0u));
     tus[t].max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
     total += uint64_t(b.width) * b.height;
   }

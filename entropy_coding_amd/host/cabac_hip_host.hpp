@@ -136,8 +136,8 @@ public:
   std::vector<uint64_t> estimate(const std::vector<EstimateJob> &jobs);
 
   // Residual binariser: the bin records CABACWriter::residual_coding (cabac_writer.cpp:2424-2525) would ask its bin
-  // encoder for, for many transform blocks in one launch.  Regular residual coding only (no transform-skip residual,
-  // no SBT/MTS zero-out, no range-extension Rice derivation).  Throws Exception("Coefficient coding called for empty
+  // encoder for, for many transform blocks in one launch.  Regular and transform-skip residual coding (no SBT/MTS
+  // zero-out, no range-extension Rice derivation).  Throws Exception("Coefficient coding called for empty
   // TU") for an all-zero block, as the reference's CHECK does (cabac_writer.cpp:2458).
   struct ResidualBlock {
     const int32_t *coeff;  // width * height coefficients, raster (TransformUnit::getCoeffs(compID).buf)
@@ -145,7 +145,9 @@ public:
     bool chroma;           // toChannelType(compID) == CHANNEL_TYPE_CHROMA
     bool depQuant;         // Slice::getDepQuantEnabledFlag
     bool signHiding;       // Slice::getSignDataHidingEnabledFlag
-    bool tsFlag;           // TU::isTSAllowed: code transform_skip_flag = 0 first
+    bool tsFlag;           // TU::isTSAllowed: code transform_skip_flag first (1 for a transform-skip block)
+    bool transformSkip = false;  // mtsIdx == MTS_SKIP with TS residual coding enabled: residual_codingTS
+    bool bdpcm = false;          // with transformSkip: cu.bdpcmMode / bdpcmModeChroma
     int maxLog2TrDynamicRange = 15;
   };
   struct ResidualResult {

@@ -170,8 +170,8 @@ private:
 // same bins into the bin encoder, same CUCtx side effects.  `residual_coding` is the drop-in for one block (one launch
 // per call: for checking, not for speed); `queue` + `flush` is the shape a writer uses — blocks queued while the
 // syntax walk runs, one launch for all of them, each block's bins handed to the encoder in order.
-// Covered: regular residual coding.  Not covered (throws): transform-skip residual coding (residual_codingTS), the
-// SBT/MTS zero-out of last_sig_coeff, and the range extensions (Rice extension, persistent Rice adaptation).
+// Covered: regular and transform-skip residual coding (with BDPCM).  Not covered (throws): the SBT/MTS zero-out of
+// last_sig_coeff and the range extensions (Rice extension, persistent Rice adaptation, TSRC Rice).
 class ResidualCoderHipRef {
 public:
   ResidualCoderHipRef(HipBatch &batch, EntropyCoding::BinEncIf &enc) : m_batch(batch), m_enc(enc) {}
@@ -189,10 +189,11 @@ public:
     it.tsFlag = tu.mtsIdx[compID] == MTS_SKIP ? 1 : 0;
     it.chroma = !isLuma(compID);
     const SPS &sps = *tu.cs->sps;
-    HIPREF_CHECK(tu.mtsIdx[compID] == MTS_SKIP && !tu.cs->slice->getTSResidualCodingDisabledFlag(),
-                 "transform-skip residual coding is not covered by the GPU binariser");
+    it.transformSkip = tu.mtsIdx[compID] == MTS_SKIP && !tu.cs->slice->getTSResidualCodingDisabledFlag();  // :2434-2438
+    it.bdpcm = (isLuma(compID) ? tu.cu->bdpcmMode : tu.cu->bdpcmModeChroma) != 0;
     HIPREF_CHECK(sps.getSpsRangeExtension().getRrcRiceExtensionEnableFlag() ||
-                     sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag(),
+                     sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag() ||
+                     (it.transformSkip && sps.getSpsRangeExtension().getTSRCRicePresentFlag()),
                  "range-extension Rice derivation is not covered by the GPU binariser");
     HIPREF_CHECK(sps.getUseMTS() && tu.cu->sbtInfo != 0, "SBT zero-out is not covered by the GPU binariser");
     const CompArea &blk = tu.blocks[compID];
@@ -219,7 +220,9 @@ public:
       b.chroma = it.chroma;
       b.depQuant = it.depQuant;
       b.signHiding = it.signHiding;
-      b.tsFlag = false;  // coded below through the encoder: its value need not be 0 here
+      b.tsFlag = false;  // coded below through the encoder
+      b.transformSkip = it.transformSkip;
+      b.bdpcm = it.bdpcm;
       b.maxLog2TrDynamicRange = it.maxLog2;
       blocks.push_back(b);
     }
@@ -257,7 +260,7 @@ private:
   struct Item {
     std::vector<int32_t> coeff;
     unsigned width = 0, height = 0;
-    bool chroma = false, depQuant = false, signHiding = false, tsAllowed = false, notSkip = true;
+    bool chroma = false, depQuant = false, signHiding = false, tsAllowed = false, notSkip = true, transformSkip = false, bdpcm = false;
     unsigned tsFlag = 0;
     int maxLog2 = 15;
     Common::CUCtx *cuCtx = nullptr;

@@ -144,6 +144,19 @@ def residual(ref):
         meta.append((int(np.log2(w)), int(np.log2(h)), chroma, flags))
         coeffs.append(c.ravel())
         recs.append(r)
+    # transform-skip blocks (residual_codingTS), with and without BDPCM / ts_flag
+    for i, (w, h) in enumerate([(w, h) for w in (2, 4, 8, 16, 32) for h in (2, 4, 8, 16, 32)] * 2):
+        kind = i % 4
+        c = ((rng.random((h, w)) < [0.3, 1.0, 0.8, 0.05][kind]) *
+             rng.integers(-[4, 40, 3, 3000][kind], [4, 40, 3, 3000][kind] + 1, (h, w))).astype(np.int32)
+        if not c.any():
+            c[0, 0] = -1
+        chroma = int(rng.integers(0, 2))
+        flags = H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, H.TU_BDPCM, 0][i % 3] | int(rng.integers(0, 4))
+        r, _ = ref.residual_records(c, chroma, flags)
+        meta.append((int(np.log2(w)), int(np.log2(h)), chroma, flags))
+        coeffs.append(c.ravel())
+        recs.append(r)
     out = {"n_blocks": np.array([len(meta)], np.int32), "meta": np.array(meta, np.int32),
            "coeff": np.concatenate(coeffs).astype(np.int32),
            "coeff_off": np.concatenate([[0], np.cumsum([len(c) for c in coeffs])]).astype(np.int64),

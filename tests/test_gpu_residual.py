@@ -213,3 +213,45 @@ def test_host_pointer_batch_api(hip):
     tus3 = tus2.copy(); tus3[2]["coeff_offset"] = len(coeff2)
     with pytest.raises(capi.CabacHipError):
         hip.residual_batch(tus3, coeff2)
+
+
+def _ts_block(rng, w, h, kind):
+    if kind == 0:
+        c = (rng.random((h, w)) < 0.3) * rng.integers(-4, 5, (h, w))
+    elif kind == 1:
+        c = rng.integers(-40, 41, (h, w))
+    elif kind == 2:
+        c = np.repeat(rng.integers(-3, 4, (h, 1)), w, 1) * (rng.random((h, w)) < 0.8)
+    else:
+        c = (rng.random((h, w)) < 0.05) * rng.integers(-3000, 3000, (h, w))
+    c = c.astype(np.int32)
+    if not c.any():
+        c[rng.integers(0, h), rng.integers(0, w)] = 1
+    return c
+
+
+def test_transform_skip_blocks(hip):
+    """residual_codingTS on the device against the oracle (pinned to the reference by test_residual_oracle.py), transform-skip
+    and regular blocks mixed in one batch, BDPCM, budget exhaustion, escapes; a 64-wide TS block is refused."""
+    rng = np.random.default_rng(0x7575)
+    blocks, chromas, flags = [], [], []
+    for w in (1, 2, 4, 8, 16, 32):
+        for h in (1, 2, 4, 8, 16, 32):
+            for k in range(6):
+                blocks.append(_ts_block(rng, w, h, k % 4))
+                chromas.append(int(rng.integers(0, 2)))
+                flags.append(H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, H.TU_BDPCM, 0][k % 3] | int(rng.integers(0, 4)))
+            blocks.append(H.random_block(rng, w, h, density=0.5, big=0.1))      # a regular block in between
+            chromas.append(0)
+            flags.append(int(rng.integers(0, 8)))
+    for w, h in [(4, 4), (32, 32), (8, 16)]:
+        for v in (1, -7, 2000, -32768):
+            c = np.full((h, w), v, np.int32)
+            c[::2, 1::2] = -v if v != -32768 else 32767
+            for fl in (H.TU_TRANSFORM_SKIP | H.TU_TS_FLAG, H.TU_TRANSFORM_SKIP | H.TU_BDPCM):
+                blocks.append(c); chromas.append(0); flags.append(fl)
+    order = rng.permutation(len(blocks))
+    check_against_oracle(hip, [blocks[i] for i in order], [chromas[i] for i in order], [flags[i] for i in order], slack=2)
+    tus, coeff = make_tus([np.ones((8, 64), np.int32)], [0], [H.TU_TRANSFORM_SKIP])
+    recs, info = residual(hip, tus, coeff)
+    assert len(recs[0]) == 0 and int(info[0]) == H.TU_INFO_BAD_DESC

@@ -132,6 +132,26 @@ def test_residual_coding_through_the_gpu_binariser_matches_reference_writer(adp,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rig_flags", [0x14, 0x10, 0x30, 0x17])
+def test_transform_skip_residual_through_the_gpu_binariser_matches_reference_writer(adp, rig_flags):
+    """mtsIdx == MTS_SKIP (rig bit 4; bit 5 BDPCM, bit 2 transform skip enabled in the SPS so that ts_flag is coded):
+    CABACWriter::residual_coding takes its residual_codingTS branch; ResidualCoderHipRef must produce the same bytes."""
+    rng = np.random.default_rng(0x7A + rig_flags)
+    blocks, comps = [], []
+    for k in range(30):
+        w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (4, 16), (2, 8)][k % 7]
+        kind = k % 4
+        c = ((rng.random((h, w)) < [0.3, 1.0, 0.8, 0.05][kind]) * rng.integers(-[4, 40, 3, 3000][kind], [4, 40, 3, 3000][kind] + 1, (h, w))).astype(np.int32)
+        if not c.any():
+            c[0, 0] = 1
+        blocks.append(c)
+        comps.append(int(rng.integers(0, 3)))
+    want, cu_want = _residual(adp, 0, blocks, comps, rig_flags)
+    many, cu_many = _residual(adp, 2, blocks, comps, rig_flags)
+    assert np.array_equal(many, want) and np.array_equal(cu_many, cu_want)
+
+
+@pytest.mark.gpu
 def test_residual_adapter_empty_block_throws_like_the_reference(adp):
     z = [np.zeros((8, 8), np.int32)]
     for which in (0, 1):
