@@ -27,10 +27,6 @@ struct cabac_hip_ctx {
   // staging for the host-pointer entry points (grown on demand)
   void *d_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [5]: scratch of the residual binariser
   size_t d_cap[6] = {0, 0, 0, 0, 0, 0};
-  // the block ordering d_buf[5] holds: built by the last sizing pass over (res_tus, res_n)
-  const void *res_tus = nullptr;
-  uint32_t res_n = 0;
-  void *res_scratch = nullptr;
 };
 
 namespace {
@@ -449,15 +445,10 @@ int cabac_hip_residual_device(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_de
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
   if (int rc = ensure(c, 5, cabac::residual_scratch_bytes(n_tu))) return rc;
-  // the writing pass reuses the ordering its sizing pass built (same descriptors, same count, same scratch)
-  const bool reuse = d_records && n_tu && c->res_tus == d_tu && c->res_n == n_tu && c->res_scratch == c->d_buf[5];
   Bracket br = bracket_for(c, 5);
   HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records,
-                                    c->d_buf[5], reuse));
-  c->res_tus = d_tu;
-  c->res_n = n_tu;
-  c->res_scratch = c->d_buf[5];
+                                    c->d_buf[5]));
   HIP_TRY(c, hipEventRecord(br.b, c->stream));
   c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;

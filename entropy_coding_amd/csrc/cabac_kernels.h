@@ -34,12 +34,11 @@ hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_of
                            const uint64_t *rec_offset, uint32_t *n_records, uint16_t *records);
 
 // residual binariser (cabac_residual.hip)
-// scratch: residual_scratch_bytes(n_tu) bytes of device memory holding the block ordering; reuse_order: the
-// scratch still holds the ordering an earlier launch with the same n_tu built (pass 2 after pass 1)
+// scratch: residual_scratch_bytes(n_tu) bytes of device memory the launch may overwrite (block ordering)
 size_t residual_scratch_bytes(uint32_t n_tu);
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
-                           void *scratch, bool reuse_order);
+                           void *scratch);
 
 // substream assembly (cabac_assemble.hip)
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,

@@ -153,8 +153,10 @@ __device__ __forceinline__ uint32_t size_class(const cabac_tu_desc &d) {
 }
 
 constexpr uint32_t kClasses = 8;
-// scratch layout (uint32): [0..7] blocks per class, [8..15] scatter cursors, [16..] permutation (padded per class)
-constexpr uint32_t kScratchHeader = 16;
+// scratch layout (uint32): [0..7] blocks per class, [8..15] scatter cursors, [16] non-zero if any block is transform-skip
+// coded, [24..] permutation (padded per class)
+constexpr uint32_t kScratchHeader = 24;
+constexpr uint32_t kScratchAnyTs = 16;
 
 // Pre-pass: each thread looks at kSortItems descriptors and keeps its per-class counts as 4-bit fields of one word
 // (a count is at most 8); counts meet through wave shuffles of 16-bit pairs, then one LDS add per wave and class,
@@ -183,11 +185,16 @@ __global__ __launch_bounds__(256) void class_hist(uint32_t n_tu, const cabac_tu_
   if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
   __syncthreads();
   uint32_t nib = 0;
+  bool ts = false;
 #pragma unroll
   for (uint32_t k = 0; k < kSortItems; k++) {
     const uint32_t i = blockIdx.x * kSortSpan + k * 256u + threadIdx.x;
-    if (i < n_tu) nib += 1u << (4u * class_of(tus, i));
+    if (i < n_tu) {
+      nib += 1u << (4u * class_of(tus, i));
+      ts = ts || (reinterpret_cast<const uint8_t *>(tus + i)[11] & CABAC_TU_TRANSFORM_SKIP);
+    }
   }
+  if (__ballot(ts) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(&scratch[kScratchAnyTs], 1u);
   uint32_t c[4];
   widen_counts(nib, c);
 #pragma unroll
@@ -278,7 +285,9 @@ __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_
 // to LDS.  Read straight from memory in scan order such a block costs a line per 16 bytes used, and with every wave
 // of an XCD holding four of them the lines do not survive in L2 between uses (measured: 10 x the block's bytes).
 // Smaller blocks fit a line or two and are read directly.
-template <bool kWrite, bool kStage>
+// kTs: the transform-skip walk (residual_codingTS) for the blocks flagged CABAC_TU_TRANSFORM_SKIP, which the other
+// variants leave alone: a launch of its own, so that its registers and code do not weigh on the regular walk.
+template <bool kWrite, bool kStage, bool kTs>
 __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage, uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                               const int32_t *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
                                               uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
@@ -299,6 +308,8 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     max_log2 = d.max_log2_tr_range ? d.max_log2_tr_range : 15u;
     coeff = coeff_all + d.coeff_offset;
   }
+  const bool mine = live && (((flags & CABAC_TU_TRANSFORM_SKIP) != 0u) == kTs);  // the other launch's rows are not touched
+  live = mine;
   const bool bad = live && (lw > 6u || lh > 6u || chroma > 1u || max_log2 > 20u ||
                             ((flags & CABAC_TU_TRANSFORM_SKIP) && (lw > 5u || lh > 5u)));  // TS blocks are at most 32 x 32
   if (bad) lw = lh = chroma = 0;
@@ -377,12 +388,12 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   uint32_t info = live ? (uint32_t)last : (bad ? CABAC_TU_INFO_BAD_DESC : empty ? CABAC_TU_INFO_EMPTY : 0u);
 
   // ---- ts_flag and the last position ------------------------------------------------------------------
-  const bool is_ts = live && (flags & CABAC_TU_TRANSFORM_SKIP);
+  const bool is_ts = kTs && live;
   if (live && (flags & CABAC_TU_TS_FLAG)) {
     if (kWrite && l == 0u) out[0] = (uint16_t)((is_ts ? CABAC_REC_BIN : 0u) | CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma));
     off = 1;
   }
-  if (live && !is_ts) {
+  if (!kTs && live) {
     const uint32_t lcg = (uint32_t)last >> cg_l2;
     const uint32_t lgp = grid[lcg];
     const uint32_t lin = c_diag.in_cg[cgw_l2][cgh_l2][(uint32_t)last & (cg_size - 1u)];
@@ -404,13 +415,13 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   }
 
   // ---- sweep 2: the coefficient groups in coding order ----------------------------------------------
-  const bool dq = live && !is_ts && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
+  const bool dq = !kTs && live && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
   int budget = (int)((we * he * 28u) >> 4);              // cabac_writer.cpp:2485-2489
   uint32_t state = 0;
   const int last_cg = live ? (last >> cg_l2) : -1;
   // Only groups that hold a coefficient (and group 0) are walked; the empty ones in between cost one group flag
   // each, written sixteen at a time.  `todo` = the groups this row still has to walk, by scan index.
-  uint64_t todo = (live && !is_ts) ? ((coded | 1ull) & ((2ull << last_cg) - 1ull)) : 0ull;
+  uint64_t todo = (!kTs && live) ? ((coded | 1ull) & ((2ull << last_cg) - 1ull)) : 0ull;
   int prev_cg = last_cg + 1;
 
   while (__ballot(todo != 0ull) != 0ull) {
@@ -593,7 +604,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   // level is mapped through its neighbours (deriveModCoeff, context_modelling.hpp:344-364).  Budget: 7/4 context bins
   // per sample for the block, checked before every position of pass 1 (sig, sign, >1, parity) and of pass 2 (up to
   // four greater-than flags): both are prefix sums over the lanes below.
-  if (__ballot(is_ts) != 0ull) {
+  if (kTs && __ballot(is_ts) != 0ull) {
     const bool bdpcm = (flags & CABAC_TU_BDPCM) != 0u;
     int tbudget = (int)((w * h * 7u) >> 2);
     uint32_t top = is_ts ? n_cg : 0u;
@@ -700,7 +711,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     }
   }
 
-  if (tu_idx < n_tu && l == 0u) {
+  if (mine && l == 0u) {
     n_records[tu_idx] = off;
     if (info_out) info_out[tu_idx] = info;
   }
@@ -723,10 +734,25 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   const uint32_t big_wgs = (((class_count[7] + r) & ~r) + ((class_count[6] + r) & ~r) + ((class_count[5] + r) & ~r)) / kRowsPerBlock;
   if (kStage) {
     for (uint32_t wg = blockIdx.x; wg < big_wgs; wg += gridDim.x)
-      residual_rows<kWrite, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, true, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   } else if (blockIdx.x >= big_wgs) {
-    residual_rows<kWrite, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+    residual_rows<kWrite, false, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   }
+}
+
+// Transform-skip blocks: a small grid that leaves at once when the batch holds none (the ordering pre-pass notes it),
+// and otherwise goes over all row groups, taking the flagged blocks.
+template <bool kWrite>
+__global__ __launch_bounds__(256) void residual_ts_kernel(uint32_t n_tu, uint32_t n_wg, const cabac_tu_desc *__restrict__ tus,
+                                                           const int32_t *__restrict__ coeff_all,
+                                                           const uint64_t *__restrict__ rec_offset,
+                                                           uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
+                                                           uint16_t *__restrict__ records, const uint32_t *__restrict__ perm,
+                                                           const uint32_t *__restrict__ header) {
+  __shared__ int32_t stage[1];
+  if (header[kScratchAnyTs] == 0u) return;
+  for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x)
+    residual_rows<kWrite, false, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
 }
 
 size_t residual_scratch_bytes(uint32_t n_tu) {
@@ -735,12 +761,12 @@ size_t residual_scratch_bytes(uint32_t n_tu) {
 
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
-                           void *scratch, bool reuse_order) {
+                           void *scratch) {
   if (n_tu == 0) return hipSuccess;
   // blocks ordered by group count: [counts | cursors | permutation, 0xFFFFFFFF where a class is padded to 16 rows]
   uint32_t *s32 = static_cast<uint32_t *>(scratch);
   const uint32_t rows = n_tu + kClasses * kRowsPerBlock;  // upper bound of the padded list
-  if (!reuse_order) {  // any complete permutation of the n_tu blocks is correct; this one balances the waves
+  {  // any complete permutation of the n_tu blocks is correct; this one balances the waves
     hipError_t e = hipMemsetAsync(s32, 0, sizeof(uint32_t) * kScratchHeader, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
@@ -757,11 +783,15 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
                        records, order, s32);
     hipLaunchKernelGGL((residual_kernel<true, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
+    hipLaunchKernelGGL((residual_ts_kernel<true>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
+                       info, records, order, s32);
   } else {
     hipLaunchKernelGGL((residual_kernel<false, true>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
     hipLaunchKernelGGL((residual_kernel<false, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
+    hipLaunchKernelGGL((residual_ts_kernel<false>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
+                       info, records, order, s32);
   }
   return hipGetLastError();
 }
