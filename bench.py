@@ -104,9 +104,10 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
     workload.RESIDUAL_TILE_MIX (`unique` generated tiles, replicated on the device).  Checked against the md5 the
     compiled reference produced for the first blocks (tests/golden/residual_bench.json) and replica against replica."""
     import torch
-    from entropy_coding_amd import workload as W
+    from entropy_coding_amd import capi, workload as W
     unique = min(unique, n_tiles)
     copies = max(n_tiles // unique, 1)
+    n_tiles = copies * unique
     tus, coeff, tile_first = W.build_residual_tiles(unique)
     n_u, c_u = len(tus), len(coeff)
     all_tus = np.tile(tus, copies)
@@ -122,21 +123,59 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
         hip.residual_device(n, t_tu.data_ptr(), t_co.data_ptr(), 0, t_cnt.data_ptr(), t_info.data_ptr(), 0)
     hip.synchronize()
     cnt = t_cnt.to(torch.int64)
-    t_off = torch.cumsum(cnt, 0) - cnt
+    # one substream per tile: its blocks' records back to back, then TRM(1)
+    per_tile = n_u // unique
+    tile_of = torch.arange(n, device="cuda") // per_tile
+    t_off = torch.cumsum(cnt, 0) - cnt + tile_of
     n_bins = int(cnt.sum().item())
-    t_rec = torch.zeros(n_bins, dtype=torch.int16, device="cuda")
+    t_rec = torch.zeros(n_bins + n_tiles, dtype=torch.int16, device="cuda")
+    tile_bins = cnt.view(n_tiles, per_tile).sum(1)
+    sub_first = torch.cumsum(tile_bins + 1, 0) - (tile_bins + 1)
+    t_rec[sub_first + tile_bins] = -32257  # 0x81FF: TRM(1)
     torch.cuda.synchronize()
     for _ in range(reps + 1):
         hip.residual_device(n, t_tu.data_ptr(), t_co.data_ptr(), t_off.data_ptr(), t_cnt.data_ptr(), t_info.data_ptr(),
                             t_rec.data_ptr())
     prof = [ms for k, ms in hip.profile_read() if k == 5]
     p1, p2 = float(np.mean(prof[1:reps + 1])), float(np.mean(prof[reps + 2:]))
-    per = n_bins // copies
-    ok = n_bins == per * copies and all(bool(torch.equal(t_rec[:per], t_rec[r * per:(r + 1) * per])) for r in range(1, copies))
+    per = (n_bins + n_tiles) // copies
+    ok = (n_bins + n_tiles) == per * copies and all(bool(torch.equal(t_rec[:per], t_rec[r * per:(r + 1) * per])) for r in range(1, copies))
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "residual_bench.json")))
     k = gold["n_blocks"]
+    assert k <= per_tile
     first = t_rec[: int(cnt[:k].sum().item())].cpu().numpy().view(np.uint16)
     ok = ok and hashlib.md5(first.tobytes()).hexdigest() == gold["records_md5"] and not bool((t_info < 0).any().item())
+    # ... and on through the bin encoder: coefficients -> bytes without leaving the device; decode gives the bins back
+    desc = np.zeros(n_tiles, capi.DESC_DTYPE)
+    lens = (tile_bins + 1).cpu().numpy().astype(np.uint64)
+    desc["n_records"] = lens
+    desc["rec_offset"] = sub_first.cpu().numpy().astype(np.uint64)
+    cap = ((lens * 3) // 4 + 64 + 15) // 16 * 16
+    desc["byte_capacity"] = cap
+    desc["byte_offset"] = np.concatenate([[0], np.cumsum(cap)[:-1]])
+    desc["qp"] = 32
+    desc["init_id"] = 2 | capi.SUB_FINISH | capi.SUB_ALIGN_RBSP
+    t_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).cuda()
+    t_bytes = torch.zeros(int(cap.sum()), dtype=torch.uint8, device="cuda")
+    t_res = torch.zeros(2 * n_tiles, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.profile_enable(reps + 1)
+    for _ in range(reps + 1):
+        hip.encode_device(n_tiles, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res.data_ptr())
+    enc = float(np.mean([ms for kk, ms in hip.profile_read() if kk == 0][1:]))
+    res = t_res.cpu().numpy().view(capi.RESULT_DTYPE)
+    ddesc = desc.copy()
+    ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
+    t_ddesc = torch.from_numpy(ddesc.view(np.uint8).reshape(-1).copy()).cuda()
+    t_bins = torch.zeros(n_bins + n_tiles, dtype=torch.uint8, device="cuda")
+    t_res_d = torch.zeros(2 * n_tiles, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.decode_device(n_tiles, t_ddesc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_bins.data_ptr(), t_res_d.data_ptr())
+    hip.synchronize()
+    round_trip = (not res["flags"].any() and not t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)["flags"].any()
+                  and bool(torch.equal(t_bins, (t_rec < 0).to(torch.uint8))))
+    ok = ok and round_trip
+    out_bytes = int(((res["n_bits"].astype(np.int64) + 7) // 8).sum())
     n_coef = c_u * copies
     bytes1 = 4 * n_coef + (16 + 4 + 4) * n
     bytes2 = 4 * n_coef + 2 * n_bins + (16 + 8 + 4 + 4) * n
@@ -150,6 +189,9 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
             # PMC bytes per launch of residual_kernel<false> / <true> (profiles/pmc_traffic.json), the ordering pre-pass apart
             "traffic": {"pass1_count": measured_traffic("C4", "residual_kernel_count"),
                         "pass2_write": measured_traffic("C4", "residual_kernel_write")},
+            # the same records through the bin encoder (one substream per tile, TRM-terminated), decoded back
+            "to_bytes": {"encode_kernel_ms": round(enc, 4), "coefficients_to_bytes_ms": round(p1 + p2 + enc, 4),
+                         "bitstream_bytes": out_bytes, "round_trip": bool(round_trip)},
             "records_match_reference": bool(ok)}
 
 
