@@ -255,3 +255,27 @@ def test_transform_skip_blocks(hip):
     tus, coeff = make_tus([np.ones((8, 64), np.int32)], [0], [H.TU_TRANSFORM_SKIP])
     recs, info = residual(hip, tus, coeff)
     assert len(recs[0]) == 0 and int(info[0]) == H.TU_INFO_BAD_DESC
+
+
+def test_many_random_blocks_of_every_kind(hip):
+    """40 000 blocks — every shape, regular and transform-skip, all flag combinations, sparse to saturated — in one
+    batch (so that every launch variant, the ordering pre-pass with all classes, staged and direct rows, and rows of
+    different kinds inside one wave are exercised) against the oracle."""
+    rng = np.random.default_rng(0xA11)
+    shapes = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
+    weights = np.array([1.0 / (1 + (w * h) / 64.0) for w, h in shapes])
+    weights /= weights.sum()
+    blocks, chromas, flags = [], [], []
+    for i in range(40000):
+        w, h = shapes[int(rng.choice(len(shapes), p=weights))]
+        ts = max(w, h) <= 32 and rng.random() < 0.25
+        if ts:
+            blocks.append(_ts_block(rng, w, h, int(rng.integers(0, 4))))
+            flags.append(H.TU_TRANSFORM_SKIP | int(rng.choice([H.TU_TS_FLAG, H.TU_BDPCM, 0])) | int(rng.integers(0, 4)))
+        else:
+            blocks.append(H.random_block(rng, w, h, density=float(rng.choice([0.05, 0.3, 0.7, 1.0])), big=float(rng.choice([0.0, 0.05, 0.3])),
+                                         huge=0.02 if rng.random() < 0.1 else 0.0, last_frac=float(rng.choice([1.0, 0.5, 0.2]))))
+            fl = int(rng.integers(0, 8))
+            flags.append(fl & ~H.TU_TS_FLAG if max(w, h) > 32 else fl)
+        chromas.append(int(rng.integers(0, 2)))
+    check_against_oracle(hip, blocks, chromas, flags)
