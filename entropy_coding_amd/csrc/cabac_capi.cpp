@@ -292,7 +292,11 @@ int cabac_hip_assemble_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subs
   if (!c || !d_offsets || (n_sub && (!d_desc || !d_results || !d_bytes || !d_payload)))
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 6);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_assemble(c->stream, n_sub, d_desc, d_results, d_bytes, d_payload, payload_capacity, d_offsets));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 
@@ -300,7 +304,11 @@ int cabac_hip_split_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
                            const uint8_t *d_payload, uint8_t *d_bytes) {
   if (!c || (n_sub && (!d_desc || !d_offsets || !d_payload || !d_bytes))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 7);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_split(c->stream, n_sub, d_desc, d_offsets, d_payload, d_bytes));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 
@@ -309,7 +317,11 @@ int cabac_hip_count_emulations_device(cabac_hip_ctx *c, uint32_t n_sub, const ca
                                       uint32_t *d_counts) {
   if (!c || (n_sub && (!d_desc || !d_results || !d_bytes || !d_counts))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 8);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
   HIP_TRY(c, cabac::launch_count_emulations(c->stream, n_sub, d_desc, d_results, d_bytes, d_counts));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 

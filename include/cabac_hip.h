@@ -310,10 +310,10 @@ int cabac_hip_residual_batch(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_d
                              uint64_t records_capacity);
 
 /* ---- per-launch timing (HIP events on the ctx stream) ----------------
- * cabac_hip_profile_enable(ctx, capacity): from now on every encode/decode/binarize/estimate device call is
+ * cabac_hip_profile_enable(ctx, capacity): from now on every device call (encode, decode, binarize, ...) is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
  * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
- * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual) and ms[i] for the recorded calls in launch order,
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual, 6 assemble, 7 split, 8 count_emulations) and ms[i] for the recorded calls in launch order,
  * returns their number and resets the ring.                                 */
 int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
 int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);
