@@ -78,27 +78,40 @@ __global__ __launch_bounds__(256) void copy_substreams_kernel(uint32_t n_sub, co
 }
 
 // countStartCodeEmulations, bit_stream.cpp:157-181: greedy, non-overlapping 00 00 {00..03} matches; the byte
-// after a match may start the next one.  One lane per substream (streams are a few KB).
-__global__ __launch_bounds__(64) void count_emulations_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
-                                                              const cabac_substream_result *__restrict__ results,
-                                                              const uint8_t *__restrict__ bytes, uint32_t *__restrict__ counts) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// after a match may start the next one, i.e. after a match the zero count restarts at this byte.  In a run of L
+// zeros that makes the 3rd, 5th, 7th ... zero a match, and leaves "two zeros seen" after the run iff L is even; a
+// following byte 1..3 then matches once more.  So a byte's fate depends only on the length k of the zero run that
+// ends at it (or just before it): one wave per substream, 64 bytes per step, k from the ballot of the zero bytes
+// (count of ones ending at the lane's bit) plus the run length carried in from the previous step.
+__global__ __launch_bounds__(256) void count_emulations_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                               const cabac_substream_result *__restrict__ results,
+                                                               const uint8_t *__restrict__ bytes, uint32_t *__restrict__ counts) {
+  const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (s >= n_sub) return;
   const uint8_t *p = bytes + desc[s].byte_offset;
   uint32_t n = (results[s].n_bits + 7u) >> 3;  // FIFO bytes (a trailing partial byte counts as held bits in the
   if (results[s].n_bits & 7u) n -= 1;           // reference and is not part of the FIFO)
-  uint32_t cnt = 0, zeros = 0;
-  // search_n(found, end - 1, 2, 0): the pair of zeros must lie in [0, n-1), the third byte is p[i]
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t b = p[i];
-    if (zeros >= 2 && b <= 3) {
-      cnt++;
-      zeros = (b == 0) ? 1 : 0;  // the scan resumes AT this byte
-    } else {
-      zeros = (b == 0) ? zeros + 1 : 0;
-    }
+  uint32_t cnt = 0, carry = 0;                  // carry: length of the zero run that ends at the last byte seen
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool in = i < n;
+    const uint32_t b = in ? p[i] : 0xffu;
+    const uint64_t zmask = __ballot(in && b == 0u);
+    // zero run ending at this lane (0 if the byte is not zero), and the one ending just before it; a run that
+    // reaches the first byte of this step continues the one carried in
+    const uint64_t not_here = ~(zmask << (63u - lane));                    // bit 63 = this lane, 0 where the byte is zero
+    const uint32_t ones = not_here ? (uint32_t)__builtin_clzll(not_here) : 64u;
+    const uint32_t k_here = ones > lane ? lane + 1u + carry : ones;
+    const uint64_t not_before = lane ? ~(zmask << (64u - lane)) : ~0ull;   // bit 63 = lane - 1
+    const uint32_t ones_b = not_before ? (uint32_t)__builtin_clzll(not_before) : 64u;
+    const uint32_t k_prev = ones_b >= lane ? lane + carry : ones_b;
+    const bool match = in && (b == 0u ? (k_here >= 3u && (k_here & 1u)) : (b <= 3u && k_prev >= 2u && !(k_prev & 1u)));
+    cnt += (uint32_t)__builtin_popcountll(__ballot(match));
+    // the run that ends at the last byte of this step
+    const uint32_t k_last = (uint32_t)__shfl((int)k_here, 63);
+    carry = k_last;
   }
-  counts[s] = cnt;
+  if (lane == 0u) counts[s] = cnt;
 }
 
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
@@ -122,7 +135,7 @@ hipError_t launch_split(hipStream_t st, uint32_t n_sub, const cabac_substream_de
 hipError_t launch_count_emulations(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                                    const cabac_substream_result *results, const uint8_t *bytes, uint32_t *counts) {
   if (n_sub)
-    hipLaunchKernelGGL(count_emulations_kernel, dim3((n_sub + 63) / 64), dim3(64), 0, st, n_sub, desc, results, bytes,
+    hipLaunchKernelGGL(count_emulations_kernel, dim3((n_sub + 3) / 4), dim3(256), 0, st, n_sub, desc, results, bytes,
                        counts);
   return hipGetLastError();
 }

@@ -55,3 +55,44 @@ def test_assemble_split_count_roundtrip():
     want_cnt = [orc.lib.orc_count_emulations(H._ptr(np.ascontiguousarray(b), H.u8p), len(b)) for b in streams]
     assert np.array_equal(cnt, np.array(want_cnt, np.int32)) and max(want_cnt) > 0
     hip.close()
+
+
+def test_count_emulations_on_crafted_zero_runs():
+    """Zero runs of every length and alignment (the kernel takes 64 bytes per step and carries the run length across
+    steps), bytes 0..4 mixed in: against the oracle's countStartCodeEmulations (pinned to the reference)."""
+    import torch
+    hip = capi.CabacHip(0)
+    orc = H.load_oracle()
+    orc.lib.orc_count_emulations.argtypes = [H.u8p, ctypes.c_long]
+    rng = np.random.default_rng(5)
+    streams = [np.zeros(n, np.uint8) for n in (0, 1, 2, 3, 4, 63, 64, 65, 127, 128, 129, 200, 1000)]
+    for k in range(600):
+        n = int(rng.integers(1, 400))
+        p0 = float(rng.choice([0.3, 0.6, 0.9, 0.98]))
+        b = rng.choice(np.array([0, 1, 2, 3, 4, 255], np.uint8), size=n, p=[p0] + [(1 - p0) / 5] * 5)
+        streams.append(b.astype(np.uint8))
+    for lead in range(0, 70, 3):           # a long run placed at every offset around the 64-byte step
+        for run in (2, 3, 4, 63, 64, 65, 130):
+            streams.append(np.concatenate([np.full(lead, 9, np.uint8), np.zeros(run, np.uint8), np.array([1, 0, 0, 2, 0, 0, 0, 3, 7], np.uint8)]))
+    n = len(streams)
+    desc = np.zeros(n, H.DESC_DTYPE)
+    cap = np.array([(len(b) + 15) // 16 * 16 + 16 for b in streams], np.uint64)
+    desc["byte_offset"] = np.concatenate([[0], np.cumsum(cap)[:-1]])
+    desc["byte_capacity"] = cap
+    res = np.zeros(n, H.RESULT_DTYPE)
+    res["n_bits"] = [8 * len(b) for b in streams]
+    buf = np.full(int(cap.sum()), 0, np.uint8)
+    for k, b in enumerate(streams):
+        buf[int(desc["byte_offset"][k]): int(desc["byte_offset"][k]) + len(b)] = b
+    t_desc = torch.from_numpy(desc.view(np.uint8).copy()).cuda()
+    t_res = torch.from_numpy(res.view(np.uint8).copy()).cuda()
+    t_buf = torch.from_numpy(buf).cuda()
+    t_cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.count_emulations_device(n, t_desc.data_ptr(), t_res.data_ptr(), t_buf.data_ptr(), t_cnt.data_ptr())
+    hip.synchronize()
+    got = t_cnt.cpu().numpy()
+    want = np.array([orc.lib.orc_count_emulations(H._ptr(np.ascontiguousarray(b), H.u8p), len(b)) for b in streams], np.int32)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    assert want.max() > 30
+    hip.close()
