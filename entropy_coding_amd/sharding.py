@@ -122,3 +122,63 @@ def encode_sharded(desc, records, encode_fn, root=0):
     d, rec, total, idx = scatter_substreams(desc, records, root)
     out, res = encode_fn(d, rec, total)
     return gather_bitstreams(int(n_total.item()), idx, d, out, res, root)
+
+
+# ---- residual binariser: transform blocks shard the same way ------------------------------------
+# The unit is a tile (a contiguous group of blocks that ends up in one substream); blocks are independent of each other,
+# so any grouping is correct — tiles keep a substream's records on one rank for the encoder that follows.
+def pack_tiles(tus, coeff, tile_first, tiles):
+    """Re-pack the blocks of `tiles` into a self-contained shard: (tus, coeff, global block indices)."""
+    blk = np.concatenate([np.arange(int(tile_first[t]), int(tile_first[t + 1]), dtype=np.int64) for t in tiles]) \
+        if len(tiles) else np.zeros(0, np.int64)
+    sub = tus[blk].copy()
+    sizes = (1 << (sub["log2_width"].astype(np.int64) + sub["log2_height"].astype(np.int64)))
+    new_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]) if len(blk) else np.zeros(0, np.int64)
+    co = np.concatenate([coeff[int(tus["coeff_offset"][b]): int(tus["coeff_offset"][b]) + int(n)] for b, n in zip(blk, sizes)]) \
+        if len(blk) else np.zeros(0, np.int32)
+    sub["coeff_offset"] = new_off
+    return sub, co.astype(np.int32), blk
+
+
+def residual_sharded(tus, coeff, tile_first, residual_fn, root=0):
+    """Scatter tiles (LPT by coefficient count) -> residual_fn(tus, coeff) -> (records, offsets, info) on every rank ->
+    gather on root in global block order.  Returns on root (list of per-block record arrays, info array); else None.
+    `residual_fn` is CabacHip.residual_batch on a GPU box; tests inject a CPU checker."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_total = torch.tensor([len(tus) if rank == root else 0], dtype=torch.int64, device=_dev())
+    dist.broadcast(n_total, root)
+    if rank == root:
+        sizes = (1 << (tus["log2_width"].astype(np.int64) + tus["log2_height"].astype(np.int64)))
+        csum = np.concatenate([[0], np.cumsum(sizes)])
+        weight = csum[np.asarray(tile_first[1:], np.int64)] - csum[np.asarray(tile_first[:-1], np.int64)]
+        owners = lpt_assign(weight, world)
+        mine = None
+        for r in range(world):
+            shard = pack_tiles(tus, coeff, tile_first, owners[r])
+            if r == root:
+                mine = shard
+            else:
+                for a in shard:
+                    _send_array(a, r)
+    else:
+        mine = (_recv_array(root, capi.TU_DTYPE).copy(), _recv_array(root, np.int32).copy(), _recv_array(root, np.int64).copy())
+    sub, co, blk = mine
+    rec, off, info = residual_fn(sub, co) if len(sub) else (np.zeros(0, np.uint16), np.zeros(1, np.uint64), np.zeros(0, np.uint32))
+    if rank != root:
+        _send_array(blk, root)
+        _send_array(np.asarray(off, np.uint64), root)
+        _send_array(np.asarray(info, np.uint32), root)
+        _send_array(np.asarray(rec, np.uint16), root)
+        return None
+    out = [None] * int(n_total.item())
+    infos = np.zeros(int(n_total.item()), np.uint32)
+    for r in range(world):
+        if r == root:
+            rblk, roff, rinfo, rrec = blk, np.asarray(off, np.uint64), np.asarray(info, np.uint32), np.asarray(rec, np.uint16)
+        else:
+            rblk, roff, rinfo, rrec = (_recv_array(r, np.int64), _recv_array(r, np.uint64), _recv_array(r, np.uint32),
+                                       _recv_array(r, np.uint16))
+        for k, g in enumerate(rblk):
+            out[int(g)] = rrec[int(roff[k]): int(roff[k + 1])].copy()
+            infos[int(g)] = rinfo[k]
+    return out, infos

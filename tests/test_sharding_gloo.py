@@ -71,3 +71,52 @@ def test_lpt_assign_balances_mixed_lengths():
     loads = [int(n[o].sum()) for o in owners]
     assert sorted(sum(owners, [])) == list(range(len(n)))
     assert max(loads) - min(loads) <= 2048 * 8
+
+
+def _orc_residual(tus, coeff):
+    """Stand-in for CabacHip.residual_batch with the same return convention."""
+    orc = H.load_oracle()
+    recs, infos = [], []
+    for d in tus:
+        w, h = 1 << int(d["log2_width"]), 1 << int(d["log2_height"])
+        c = coeff[int(d["coeff_offset"]): int(d["coeff_offset"]) + w * h].reshape(h, w)
+        r, last, mts = orc.residual_records(c, int(d["channel"]), int(d["flags"]))
+        recs.append(r)
+        infos.append(last | (H.TU_INFO_MTS_VIOLATION if mts else 0))
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    return (np.concatenate(recs) if recs else np.zeros(0, np.uint16)), off, np.array(infos, np.uint32)
+
+
+def _residual_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from entropy_coding_amd import workload as W
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tus, coeff, tile_first = W.build_residual_tiles(5) if rank == 0 else (None, None, None)
+    got = sharding.residual_sharded(tus, coeff, tile_first, _orc_residual, root=0)
+    if rank == 0:
+        recs, infos = got
+        want, off, winfo = _orc_residual(tus, coeff)
+        ok = len(recs) == len(tus) and np.array_equal(infos, winfo)
+        for b in range(len(tus)):
+            ok = ok and np.array_equal(recs[b], want[int(off[b]): int(off[b + 1])])
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_residual_tiles_scatter_binarise_gather(world):
+    """Transform blocks shard by tile like substreams do (no data-path collective): scatter, per-rank binariser, gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_residual_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
