@@ -280,14 +280,14 @@ __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_
   }
 }
 
-// kStage: the blocks of this launch (512 or 1024 coded coefficients) are first copied into LDS row by row — every
+// kStageDw != 0: the blocks of this launch (up to kStageDw coded coefficients) are first copied into LDS row by row — every
 // 128-byte line of the block is fetched once and used whole — and all later reads (scan-order walks, templates) go
 // to LDS.  Read straight from memory in scan order such a block costs a line per 16 bytes used, and with every wave
 // of an XCD holding four of them the lines do not survive in L2 between uses (measured: 10 x the block's bytes).
 // Smaller blocks fit a line or two and are read directly.
 // kTs: the transform-skip walk (residual_codingTS) for the blocks flagged CABAC_TU_TRANSFORM_SKIP, which the other
 // variants leave alone: a launch of its own, so that its registers and code do not weigh on the regular walk.
-template <bool kWrite, bool kStage, bool kTs>
+template <bool kWrite, uint32_t kStageDw, bool kTs>
 __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage, uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                               const int32_t *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
                                               uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
@@ -331,13 +331,14 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   const bool lane_in_cg = l < cg_size;
 
   const uint32_t lwe = 31u - (uint32_t)__builtin_clz(we);
-  const uint32_t stage_base = (threadIdx.x >> 4) * 1024u;
+  constexpr bool kStage = kStageDw != 0u;  // LDS dwords per row: 1024 (blocks of 512-1024 coefficients), 256, or none
+  const uint32_t stage_base = (threadIdx.x >> 4) * kStageDw;
   if (kStage) {
-    const uint32_t total = live ? we * he : 0u;  // 512 or 1024 here
+    const uint32_t total = live ? min(we * he, kStageDw) : 0u;
     uint32_t tmax = total;
     tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, 16));
     tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, 32));
-    tmax = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tmax), 1024u);
+    tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmax);
     for (uint32_t i = l; i < tmax; i += 64u) {
       int32_t v[4];
 #pragma unroll
@@ -717,10 +718,11 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   }
 }
 
-// The block order starts with the classes 7 (rejected), 6, 5: those rows are the staged launch's, a small grid whose
-// workgroups take them in turn (LDS leaves room for two workgroups per CU anyway); the direct launch has one
-// workgroup per 16 rows and the few that fall into the staged range leave at once.
-template <bool kWrite, bool kStage>
+// The block order starts with the classes 7 (rejected), 6, 5 — the rows of the launch staged with 4 KB per row — then
+// class 4 (256 coded coefficients: 1 KB per row), then the rest, read directly.  The staged launches are small grids
+// whose workgroups take their range in turn; the direct launch has one workgroup per 16 rows, and those that fall into
+// a staged range leave at once.
+template <bool kWrite, uint32_t kStageDw>
 __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                                         const int32_t *__restrict__ coeff_all,
                                                         const uint64_t *__restrict__ rec_offset,
@@ -729,14 +731,18 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
                                                         uint16_t *__restrict__ records,
                                                         const uint32_t *__restrict__ perm,
                                                         const uint32_t *__restrict__ class_count) {
-  __shared__ int32_t stage[kStage ? kRowsPerBlock * 1024u : 1u];
+  __shared__ int32_t stage[kStageDw ? kRowsPerBlock * kStageDw : 1u];
   const uint32_t r = kRowsPerBlock - 1u;
   const uint32_t big_wgs = (((class_count[7] + r) & ~r) + ((class_count[6] + r) & ~r) + ((class_count[5] + r) & ~r)) / kRowsPerBlock;
-  if (kStage) {
+  const uint32_t mid_wgs = ((class_count[4] + r) & ~r) / kRowsPerBlock;
+  if (kStageDw == 1024u) {
     for (uint32_t wg = blockIdx.x; wg < big_wgs; wg += gridDim.x)
-      residual_rows<kWrite, true, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
-  } else if (blockIdx.x >= big_wgs) {
-    residual_rows<kWrite, false, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, 1024u, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+  } else if (kStageDw == 256u) {
+    for (uint32_t wg = big_wgs + blockIdx.x; wg < big_wgs + mid_wgs; wg += gridDim.x)
+      residual_rows<kWrite, 256u, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+  } else if (blockIdx.x >= big_wgs + mid_wgs) {
+    residual_rows<kWrite, 0u, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   }
 }
 
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256) void residual_ts_kernel(uint32_t n_tu, uint32_
   __shared__ int32_t stage[1];
   if (header[kScratchAnyTs] == 0u) return;
   for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x)
-    residual_rows<kWrite, false, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+    residual_rows<kWrite, 0u, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
 }
 
 size_t residual_scratch_bytes(uint32_t n_tu) {
@@ -776,19 +782,23 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
     hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
   }
   const dim3 grid(rows / kRowsPerBlock);
-  const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u);
+  const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u), grid_mid(grid.x < 8192u ? grid.x : 8192u);
   const uint32_t *order = s32 + kScratchHeader;
   if (records) {
-    hipLaunchKernelGGL((residual_kernel<true, true>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+    hipLaunchKernelGGL((residual_kernel<true, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<true, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+    hipLaunchKernelGGL((residual_kernel<true, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+    hipLaunchKernelGGL((residual_kernel<true, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
     hipLaunchKernelGGL((residual_ts_kernel<true>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
                        info, records, order, s32);
   } else {
-    hipLaunchKernelGGL((residual_kernel<false, true>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+    hipLaunchKernelGGL((residual_kernel<false, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<false, false>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+    hipLaunchKernelGGL((residual_kernel<false, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                       records, order, s32);
+    hipLaunchKernelGGL((residual_kernel<false, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                        records, order, s32);
     hipLaunchKernelGGL((residual_ts_kernel<false>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
                        info, records, order, s32);
