@@ -1243,3 +1243,168 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
   if (info) *info = info_bits;
   return r.n;
 }
+
+/* ---------------------------------------------------------------- residual parser (decoder side)
+ * Restates CABACReader::residual_coding (cabac_reader.cpp:2647-2735), last_sig_coeff (:2865-2938) and
+ * residual_coding_subblock (:2946-3128) for regular residual coding: the context of every bin follows from the
+ * coefficients decoded so far, so no bin/context sequence is supplied.  One substream = n_tu blocks in order, then
+ * (finish != 0) encodeBinTrm(1) / finish() are checked.  coeff_out receives each block at tus[t].coeff_offset (raster,
+ * stride = width; only the coded region of a 64-wide/tall block is written).
+ * Returns 0; -2 unsupported block (transform skip, bad size); -4 read past the end; -5 missing terminate bin / stop
+ * pattern. */
+static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff) {
+  const int lw = tu->log2_width, lh = tu->log2_height, chroma = tu->channel;
+  const unsigned flags = tu->flags;
+  const int max_log2 = tu->max_log2_tr_range ? tu->max_log2_tr_range : 15;
+  if (lw > 6 || lh > 6 || chroma > 1 || (flags & CABAC_TU_TRANSFORM_SKIP)) return -2;
+  blk_geom g;
+  blk_geom_init(&g, lw, lh);
+  uint32_t *scan = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(g.w * g.h));
+  orc_scan_order(lw, lh, scan);
+#define SX(p) ((int)(scan[p] & 0xffff))
+#define SY(p) ((int)(scan[p] >> 16))
+  const int we = g.w < 32 ? g.w : 32, he = g.h < 32 ? g.h : 32;
+  memset(coeff, 0, sizeof(int32_t) * (size_t)(g.w * g.h)); /* the reader requires a zeroed block (cabac_reader.cpp:2950) */
+  if (flags & CABAC_TU_TS_FLAG) (void)dec_bin(d, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma)); /* must be 0 for these blocks */
+
+  /* last significant position */
+  static const uint8_t luma_off[7] = {0, 0, 0, 3, 6, 10, 15};
+  const unsigned off_x = chroma ? 0 : luma_off[lw], off_y = chroma ? 0 : luma_off[lh];
+  unsigned sh_x, sh_y;
+  if (chroma) {
+    sh_x = (unsigned)(g.w >> 3); if (sh_x > 2) sh_x = 2;
+    sh_y = (unsigned)(g.h >> 3); if (sh_y > 2) sh_y = 2;
+  } else {
+    sh_x = (unsigned)(lw + 1) >> 2; sh_y = (unsigned)(lh + 1) >> 2;
+  }
+  const unsigned max_x = last_group_idx((unsigned)we - 1), max_y = last_group_idx((unsigned)he - 1);
+  unsigned px = 0, py = 0;
+  while (px < max_x && dec_bin(d, CABAC_CTX_LAST_X(chroma) + off_x + (px >> sh_x))) px++;
+  while (py < max_y && dec_bin(d, CABAC_CTX_LAST_Y(chroma) + off_y + (py >> sh_y))) py++;
+  if (px > 3) px = last_min_in_group(px) + dec_bins_ep(d, (px - 2) >> 1);
+  if (py > 3) py = last_min_in_group(py) + dec_bins_ep(d, (py - 2) >> 1);
+  int last = 0;
+  for (; last < g.w * g.h - 1; last++)
+    if (SX(last) == (int)px && SY(last) == (int)py) break;
+
+  const unsigned trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u;
+  int state = 0, budget = (we * he * 28) >> 4;
+  uint8_t cg_sig[64];
+  memset(cg_sig, 0, sizeof cg_sig);
+  const int cg_size = 1 << g.cg_l2, last_cg = last >> g.cg_l2;
+  for (int cg = last_cg; cg >= 0; cg--) {
+    const int lo = cg << g.cg_l2, hi = lo + cg_size - 1;
+    const int cgx = SX(lo) >> g.cgw_l2, cgy = SY(lo) >> g.cgh_l2;
+    int sig = cg == last_cg || cg == 0;
+    if (!sig) {
+      const int right = cgx + 1 < g.wg ? cg_sig[cgy * g.wg + cgx + 1] : 0;
+      const int below = cgy + 1 < g.hg ? cg_sig[(cgy + 1) * g.wg + cgx] : 0;
+      sig = (int)dec_bin(d, CABAC_CTX_SIG_COEFF_GROUP(chroma) + (unsigned)(right | below));
+    }
+    if (!sig) continue;
+    cg_sig[cgy * g.wg + cgx] = 1;
+    const int first = cg == last_cg ? last : hi;
+    const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
+    int n_nz = 0, first_nz = first, last_nz = -1, p;
+    int nz_pos[16];
+    for (p = first; p >= lo && budget >= 4; p--) { /* pass 1 */
+      const int x = SX(p), y = SY(p), diag = x + y;
+      const tmpl_t t = tmpl_at(coeff, &g, x, y);
+      unsigned sf = (!n_nz && p == infer);
+      if (!sf) {
+        int ofs = (t.sum_clip + 1) >> 1;
+        if (ofs > 3) ofs = 3;
+        if (diag < 2) ofs += 4;
+        if (!chroma && diag < 5) ofs += 4;
+        sf = dec_bin(d, CABAC_CTX_SIG_FLAG((state > 1 ? state - 1 : 0) * 2 + chroma) + (unsigned)ofs);
+        budget--;
+      }
+      if (sf) {
+        int ofs = 0;
+        if (p != last) {
+          int s1 = t.sum_clip - t.n_nonzero;
+          ofs = (s1 < 4 ? s1 : 4) + 1;
+          if (diag == 0) ofs += chroma ? 5 : 15;
+          else if (!chroma) ofs += diag < 3 ? 10 : diag < 10 ? 5 : 0;
+        }
+        nz_pos[n_nz++] = p;
+        first_nz = p;
+        if (p > last_nz) last_nz = p;
+        const unsigned g1 = dec_bin(d, CABAC_CTX_GTX_FLAG(2 + chroma) + (unsigned)ofs);
+        unsigned par = 0, g2 = 0;
+        budget--;
+        if (g1) {
+          par = dec_bin(d, CABAC_CTX_PAR_FLAG(chroma) + (unsigned)ofs);
+          g2 = dec_bin(d, CABAC_CTX_GTX_FLAG(chroma) + (unsigned)ofs);
+          budget -= 2;
+        }
+        coeff[y * g.w + x] = (int32_t)(1 + par + g1 + (g2 << 1));
+      }
+      state = (int)((trans >> ((state << 2) + ((coeff[y * g.w + x] & 1) << 1))) & 3);
+    }
+    const int bypass_from = p;
+    for (int q = first; q > bypass_from; q--) { /* pass 2 */
+      int32_t *c = &coeff[SY(q) * g.w + SX(q)];
+      if (*c >= 4) {
+        const tmpl_t t = tmpl_at(coeff, &g, SX(q), SY(q));
+        *c += (int32_t)(dec_rem_abs(d, rice_from(t.sum_abs, 4), 5, max_log2) << 1);
+      }
+    }
+    for (int q = bypass_from; q >= lo; q--) { /* pass 3 */
+      const tmpl_t t = tmpl_at(coeff, &g, SX(q), SY(q));
+      const unsigned rice = rice_from(t.sum_abs, 0);
+      const int pos0 = (state < 2 ? 1 : 2) << rice;
+      const int rem = (int)dec_rem_abs(d, rice, 5, max_log2);
+      const int v = rem == pos0 ? 0 : rem < pos0 ? rem + 1 : rem;
+      state = (int)((trans >> ((state << 2) + ((v & 1) << 1))) & 3);
+      if (v) {
+        nz_pos[n_nz++] = q;
+        first_nz = q;
+        if (q > last_nz) last_nz = q;
+        coeff[SY(q) * g.w + SX(q)] = v;
+      }
+    }
+    const int hide = (flags & CABAC_TU_SIGN_HIDING) && last_nz - first_nz >= 4;
+    const int n_signs = hide ? n_nz - 1 : n_nz;
+    const unsigned pattern = dec_bins_ep(d, (unsigned)n_signs);
+    int sum = 0;
+    for (int k = 0; k < n_signs; k++) {
+      int32_t *c = &coeff[SY(nz_pos[k]) * g.w + SX(nz_pos[k])];
+      sum += *c;
+      if ((pattern >> (n_signs - 1 - k)) & 1) *c = -*c;
+    }
+    if (n_nz > n_signs) { /* the hidden sign is the parity of the sum of levels, cabac_reader.cpp:3120-3126 */
+      int32_t *c = &coeff[SY(nz_pos[n_signs]) * g.w + SX(nz_pos[n_signs])];
+      sum += *c;
+      if (sum & 1) *c = -*c;
+    }
+  }
+#undef SX
+#undef SY
+  free(scan);
+  return d->underrun ? -4 : 0;
+}
+
+int orc_residual_decode(const uint8_t *in, long n_in, int qp, int init_id, const void *tus_, long n_tu, int finish,
+                        int32_t *coeff_out, uint32_t *n_bits_read) {
+  const cabac_tu_desc *tus = (const cabac_tu_desc *)tus_;
+  bin_dec d;
+  memset(&d, 0, sizeof d);
+  d.in = in;
+  d.n_in = n_in;
+  ctx_store_init(&d.ctx, qp, init_id);
+  dec_start(&d);
+  for (long t = 0; t < n_tu; t++) {
+    const int rc = parse_block(&d, &tus[t], coeff_out + tus[t].coeff_offset);
+    if (rc) return rc;
+  }
+  int rc = 0;
+  if (finish) {
+    if (dec_trm(&d) != 1) rc = -5;
+    if (!rc && d.underrun) rc = -4;
+    if (!rc) rc = dec_finish(&d);
+  }
+  if (n_bits_read) *n_bits_read = (uint32_t)(8 * d.idx + d.bits_needed);
+  if (!rc && d.underrun) rc = -4;
+  return rc;
+}

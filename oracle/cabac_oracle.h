@@ -88,6 +88,13 @@ long orc_residual_records(int log2_width, int log2_height, int chroma, unsigned 
                           const int32_t *coeff, uint16_t *out, long cap, uint32_t *info);
 long orc_scan_order(int log2_width, int log2_height, uint32_t *out);
 
+/* Residual parser (CABACReader::residual_coding, cabac_reader.cpp:2647-3128, regular residual coding): bytes -> coefficient
+ * blocks; `tus` = n_tu cabac_tu_desc (include/cabac_hip.h), block t written at coeff_out + tus[t].coeff_offset.
+ * finish: expect TRM(1) and the stop pattern after the last block.  Returns 0, -2 unsupported block, -4 read past the
+ * end, -5 missing terminate bin / stop pattern. */
+int orc_residual_decode(const uint8_t *in, long n_in, int qp, int init_id, const void *tus, long n_tu, int finish,
+                        int32_t *coeff_out, uint32_t *n_bits_read);
+
 #ifdef __cplusplus
 }
 #endif

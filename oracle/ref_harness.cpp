@@ -467,4 +467,41 @@ long ref_scan_order(int width, int height, uint32_t *out) {
   return (long)width * height;
 }
 
+// The reference's own CABACReader::residual_coding (cabac_reader.cpp:2647-2735) on n blocks in one substream: sizes
+// wh[2i], wh[2i+1], component comp[i] (rig flags as ref_residual_records), coefficients written back to back into
+// coeff_out.  finish: then decodeBinTrm() must give 1 and finish() is called.
+long ref_residual_decode(int n, const int *wh, const int *comp, int rig_flags, const uint8_t *in, long n_in, int qp,
+                         int finish, int32_t *coeff_out, uint32_t *n_bits_read) {
+  try {
+    static ResidualRig rig;
+    BinDecoder_Std dec;
+    InputBitstream ib;
+    ib.getFifo().assign(in, in + n_in);
+    CABACReader r(dec);
+    r.initBitstream(&ib);
+    dec.reset(qp, 2);
+    CUCtx cuCtx(0);
+    int32_t *out = coeff_out;
+    for (int i = 0; i < n; i++) {
+      const int w = wh[2 * i], h = wh[2 * i + 1];
+      std::vector<int32_t> zeros((size_t)w * h, 0);
+      std::vector<TCoeff> buf;
+      TransformUnit tu;
+      rig.make_tu(tu, buf, w, h, comp[i], rig_flags, zeros.data());
+      r.residual_coding(tu, ComponentID(comp[i]), cuCtx);
+      for (size_t k = 0; k < buf.size(); k++) out[k] = (int32_t)buf[k];
+      out += (size_t)w * h;
+    }
+    if (finish) {
+      if (dec.decodeBinTrm() != 1) { strcpy(g_err, "terminate bin is not 1"); return -5; }
+      dec.finish();
+    }
+    if (n_bits_read) *n_bits_read = 8u * ib.getByteLocation() + (uint32_t)dec.m_bitsNeeded;
+    return 0;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
 } // extern "C"

@@ -242,6 +242,44 @@ class CodecLib:
         assert 0 <= n <= cap, n
         return out[:n].copy(), info
 
+    def residual_decode(self, data, qp, blocks_meta, finish=True):
+        """blocks_meta: [(w, h, chroma, flags)] -> (rc, [coefficient blocks (h, w)], n_bits_read)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        total = sum(w * h for w, h, _, _ in blocks_meta)
+        out = np.full(max(total, 1), 0x5A5A5A5A, np.int32)
+        nbits = ctypes.c_uint32(0)
+        if self.p == "orc_":
+            tus = np.zeros(len(blocks_meta), TU_DTYPE)
+            off = 0
+            for i, (w, h, ch, fl) in enumerate(blocks_meta):
+                tus[i]["coeff_offset"], tus[i]["log2_width"], tus[i]["log2_height"] = off, int(np.log2(w)), int(np.log2(h))
+                tus[i]["channel"], tus[i]["flags"] = ch, fl
+                off += w * h
+            f = self.lib.orc_residual_decode
+            f.restype = ctypes.c_int
+            f.argtypes = [u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, i32p, u32p]
+            rc = f(_ptr(data, u8p), len(data), qp, 2, tus.ctypes.data, len(tus), 1 if finish else 0, _ptr(out, i32p),
+                   ctypes.byref(nbits))
+        else:
+            flagsets = {fl & 3 for _, _, _, fl in blocks_meta}
+            assert len(flagsets) <= 1, "the rig has one slice: dep_quant / sign hiding must be the same for all blocks"
+            rig = (flagsets.pop() if flagsets else 0)
+            assert not any(fl & ~3 for _, _, _, fl in blocks_meta)
+            wh = np.array([[w, h] for w, h, _, _ in blocks_meta], np.int32).ravel()
+            comp = np.array([1 if ch else 0 for _, _, ch, _ in blocks_meta], np.int32)
+            ip = ctypes.POINTER(ctypes.c_int)
+            f = self.lib.ref_residual_decode
+            f.restype = ctypes.c_long
+            f.argtypes = [ctypes.c_int, ip, ip, ctypes.c_int, u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, i32p, u32p]
+            rc = f(len(blocks_meta), wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), rig, _ptr(data, u8p), len(data), qp,
+                   1 if finish else 0, _ptr(out, i32p), ctypes.byref(nbits))
+        blocks, off = [], 0
+        for w, h, _, _ in blocks_meta:
+            blocks.append(out[off:off + w * h].reshape(h, w).copy())
+            off += w * h
+        return int(rc), blocks, nbits.value
+
     def scan_order(self, w, h):
         out = np.zeros(w * h, np.uint32)
         if self.p == "orc_":

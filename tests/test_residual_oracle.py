@@ -140,3 +140,64 @@ def test_golden_blocks():
         want = g["records"][g["rec_off"][k]: g["rec_off"][k + 1]]
         got, last, mts = orc.residual_records(c, chroma, flags)
         assert np.array_equal(got, want), k
+
+
+def _encode_blocks(orc, blocks, chromas, flags, qp=32):
+    """blocks -> records (oracle, pinned above) + TRM(1) -> the substream's bytes (finish + byte alignment)."""
+    rec = np.concatenate([orc.residual_records(c, chromas[i], flags[i])[0] for i, c in enumerate(blocks)] + [np.array([0x81FF], np.uint16)])
+    data, nbits = orc.encode_records(rec, qp, 2, 3)
+    return data, len(rec)
+
+
+@needs_ref
+@pytest.mark.parametrize("flags", [0, H.TU_DEP_QUANT])
+def test_residual_parser_matches_reference_reader(flags):
+    """bytes -> coefficients: the oracle's parser against the reference's CABACReader::residual_coding, several blocks per
+    substream so that contexts and the arithmetic decoder carry over; without sign hiding the blocks come back exactly."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0xDEC + flags)
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 16), (32, 8), (2, 8), (64, 16), (1, 16), (16, 1)]
+    for trial in range(6):
+        blocks, metas = [], []
+        for k in range(14):
+            w, h = shapes[int(rng.integers(0, len(shapes)))]
+            c = H.random_block(rng, w, h, density=[0.1, 0.4, 0.9][k % 3], big=[0.0, 0.1, 0.3][k % 3],
+                               huge=0.02 if k % 7 == 6 else 0.0, last_frac=[1.0, 0.4][k % 2])
+            blocks.append(c)
+            metas.append((w, h, int(rng.integers(0, 2)), flags))
+        data, _ = _encode_blocks(orc, blocks, [m[2] for m in metas], [m[3] for m in metas])
+        rc_r, got_r, nb_r = ref.residual_decode(data, 32, metas)
+        rc_o, got_o, nb_o = orc.residual_decode(data, 32, metas)
+        assert rc_r == 0 and rc_o == 0 and nb_r == nb_o
+        for k, c in enumerate(blocks):
+            assert np.array_equal(got_o[k], got_r[k]), (trial, k, c.shape)
+            assert np.array_equal(got_o[k], c), (trial, k, c.shape)
+
+
+@needs_ref
+def test_residual_parser_with_sign_hiding_matches_reference_reader():
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0x51D)
+    for fl in (H.TU_SIGN_HIDING, H.TU_SIGN_HIDING | H.TU_DEP_QUANT):
+        blocks, metas = [], []
+        for k in range(20):
+            w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (4, 16)][k % 6]
+            blocks.append(H.random_block(rng, w, h, density=0.6, big=0.1))
+            metas.append((w, h, k & 1, fl))
+        data, _ = _encode_blocks(orc, blocks, [m[2] for m in metas], [m[3] for m in metas])
+        rc_r, got_r, nb_r = ref.residual_decode(data, 32, metas)
+        rc_o, got_o, nb_o = orc.residual_decode(data, 32, metas)
+        assert rc_r == 0 and rc_o == 0 and nb_r == nb_o
+        for k, c in enumerate(blocks):
+            assert np.array_equal(got_o[k], got_r[k]), k            # the hidden sign follows the parity rule in both
+            assert np.array_equal(np.abs(got_o[k]), np.abs(c)), k   # magnitudes always come back
+
+
+def test_residual_parser_errors():
+    orc = H.load_oracle()
+    c = np.array([[3, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 2]], np.int32)
+    data, _ = _encode_blocks(orc, [c], [0], [0])
+    rc, got, _ = orc.residual_decode(data, 32, [(4, 4, 0, 0)])
+    assert rc == 0 and np.array_equal(got[0], c)
+    assert orc.residual_decode(data[:1], 32, [(4, 4, 0, 0)])[0] == -4                 # read past the end
+    assert orc.residual_decode(data, 32, [(4, 4, 0, H.TU_TRANSFORM_SKIP)])[0] == -2   # not covered by the parser
