@@ -28,7 +28,7 @@ EXPORTS = [
     "cabac_hip_encode_bound", "cabac_hip_init", "cabac_hip_destroy", "cabac_hip_strerror",
     "cabac_hip_last_error", "cabac_hip_set_stream", "cabac_hip_synchronize", "cabac_hip_set_variant",
     "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
-    "cabac_hip_binarize_device", "cabac_hip_residual_device", "cabac_hip_residual_batch", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
+    "cabac_hip_binarize_device", "cabac_hip_residual_device", "cabac_hip_residual_batch", "cabac_hip_residual_parse_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
@@ -69,6 +69,7 @@ def load_library():
     L.cabac_hip_ctx_init_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_binarize_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.cabac_hip_residual_parse_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
@@ -217,6 +218,11 @@ class CabacHip:
         """cabac_hip_residual_device: coefficient blocks -> bin records (pass 1 when d_records == 0)."""
         self._check(self.L.cabac_hip_residual_device(self.h, n_tu, vp(d_tu), vp(d_coeff), vp(d_rec_offset),
                                                      vp(d_n_records), vp(d_info), vp(d_records)))
+
+    def residual_parse_device(self, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results):
+        """cabac_hip_residual_parse_device: bytes -> coefficient blocks, contexts derived on the device."""
+        self._check(self.L.cabac_hip_residual_parse_device(self.h, n_sub, vp(d_desc), vp(d_bytes), vp(d_tile_first), vp(d_tu),
+                                                           vp(d_coeff), vp(d_results)))
 
     def residual_batch(self, tus, coeff, check=True):
         """Host arrays in, (records, offsets, info) out (cabac_hip_residual_batch: both passes, synchronous)."""

@@ -514,4 +514,18 @@ int cabac_hip_residual_batch(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_des
   return status;
 }
 
+int cabac_hip_residual_parse_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                    const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
+                                    int32_t *d_coeff, cabac_substream_result *d_results) {
+  if (!c || (n_sub && (!d_desc || !d_bytes || !d_tile_first || !d_tu || !d_coeff || !d_results)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  Bracket br = bracket_for(c, 9);
+  HIP_TRY(c, hipEventRecord(br.a, c->stream));
+  HIP_TRY(c, cabac::launch_residual_parse(c->stream, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results));
+  HIP_TRY(c, hipEventRecord(br.b, c->stream));
+  c->timed = (br.a == c->ev_start);
+  return CABAC_HIP_OK;
+}
+
 }  // extern "C"

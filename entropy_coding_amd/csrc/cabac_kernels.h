@@ -40,6 +40,11 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
                            void *scratch);
 
+// residual parser (cabac_residual.hip): bytes -> coefficient blocks, one substream = blocks [tile_first[s], tile_first[s+1])
+hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
+                                 cabac_substream_result *results);
+
 // substream assembly (cabac_assemble.hip)
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,

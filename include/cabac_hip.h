@@ -300,6 +300,20 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
                              const uint16_t *records, uint64_t n_records_total,
                              uint64_t *frac_bits, uint32_t *flags);
 
+/* ---- residual parser on the device (decoder side) ------------------------------------
+ * CABACReader::residual_coding (cabac_reader.cpp:2647-2735) with last_sig_coeff (:2865-2938) and
+ * residual_coding_subblock (:2946-3128) on top of the bin decoder: bytes -> transform-block coefficients.  Unlike
+ * cabac_hip_decode_device no bin / context sequence is supplied: every context follows from the coefficients decoded
+ * so far; only the geometry of the blocks is given.  Substream s (desc[s]: byte_offset, byte_capacity, qp, init_id |
+ * CABAC_SUB_FINISH) holds the blocks d_tile_first[s] .. d_tile_first[s+1]-1 of d_tu in order, then — with
+ * CABAC_SUB_FINISH — the terminate bin 1 and the stop pattern, which are checked.  Block t is written to
+ * d_coeff + d_tu[t].coeff_offset (int32, raster, stride = width; of a 64-wide/tall block only the coded top-left
+ * 32 x 32).  results[s] = {bits read, CABAC_RES_UNDERRUN | CABAC_RES_BAD_STOP | CABAC_RES_BAD_RECORD (a block the
+ * parser does not cover: transform skip, bad size)}.  Regular residual coding; flags as for the binariser.        */
+int cabac_hip_residual_parse_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                    const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
+                                    int32_t *d_coeff, cabac_substream_result *d_results);
+
 /* Host-pointer form of cabac_hip_residual_device (synchronous, both passes).  `offsets` receives n_tu + 1 record
  * offsets (block t's records are records[offsets[t] .. offsets[t+1])); n_records/info as on the device, info may
  * be NULL.  If `records` is NULL or records_capacity is less than offsets[n_tu], only the sizes are produced
@@ -313,7 +327,7 @@ int cabac_hip_residual_batch(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_d
  * cabac_hip_profile_enable(ctx, capacity): from now on every device call (encode, decode, binarize, ...) is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
  * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
- * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual, 6 assemble, 7 split, 8 count_emulations) and ms[i] for the recorded calls in launch order,
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual, 6 assemble, 7 split, 8 count_emulations, 9 residual_parse) and ms[i] for the recorded calls in launch order,
  * returns their number and resets the ring.                                 */
 int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
 int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);

@@ -1,0 +1,139 @@
+"""GPU: the residual parser (cabac_hip_residual_parse_device, csrc/cabac_residual.hip) — bytes -> coefficient blocks with
+the contexts derived on the device — through the C ABI against the oracle's parser (orc_residual_decode, pinned to the
+reference's CABACReader::residual_coding by tests/test_residual_oracle.py) and against the coefficients that were coded."""
+import numpy as np
+import pytest
+
+import helpers as H
+from entropy_coding_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    c = capi.CabacHip(0)
+    yield c
+    c.close()
+
+
+def build(rng, n_sub, flags_of, qps, max_blocks=12):
+    """n_sub substreams of random blocks -> (metas per substream, blocks per substream, bytes per substream)."""
+    orc = H.load_oracle()
+    subs = []
+    for s in range(n_sub):
+        blocks, metas = [], []
+        for k in range(int(rng.integers(1, max_blocks + 1))):
+            w, h = SHAPES[int(rng.integers(0, len(SHAPES)))]
+            blocks.append(H.random_block(rng, w, h, density=float(rng.choice([0.05, 0.3, 0.7, 1.0])), big=float(rng.choice([0.0, 0.05, 0.3])),
+                                         huge=0.02 if rng.random() < 0.1 else 0.0, last_frac=float(rng.choice([1.0, 0.5, 0.2]))))
+            metas.append((w, h, int(rng.integers(0, 2)), flags_of(s)))
+        rec = np.concatenate([orc.residual_records(c, metas[i][2], metas[i][3])[0] for i, c in enumerate(blocks)] + [np.array([0x81FF], np.uint16)])
+        data, _ = orc.encode_records(rec, int(qps[s]), 2, 3)
+        subs.append((metas, blocks, data))
+    return subs
+
+
+def parse(hip, subs, qps, capacities=None, finish=True, mutate=None):
+    import torch
+    n_sub = len(subs)
+    metas = [m for s in subs for m in s[0]]
+    tus = np.zeros(len(metas), H.TU_DTYPE)
+    off = 0
+    for i, (w, h, ch, fl) in enumerate(metas):
+        tus[i]["coeff_offset"], tus[i]["log2_width"], tus[i]["log2_height"], tus[i]["channel"], tus[i]["flags"] = off, int(np.log2(w)), int(np.log2(h)), ch, fl
+        off += w * h
+    tile_first = np.concatenate([[0], np.cumsum([len(s[0]) for s in subs])]).astype(np.uint32)
+    desc = np.zeros(n_sub, H.DESC_DTYPE)
+    caps = np.array([len(s[2]) for s in subs], np.uint64) if capacities is None else np.asarray(capacities, np.uint64)
+    slots = (np.array([len(s[2]) for s in subs], np.uint64) + 15) // 16 * 16 + 16
+    desc["byte_offset"] = np.concatenate([[0], np.cumsum(slots)[:-1]])
+    desc["byte_capacity"] = caps
+    desc["qp"] = qps
+    desc["init_id"] = 2 | (H.SUB_FINISH if finish else 0)
+    buf = np.zeros(int(slots.sum()), np.uint8)
+    for s in range(n_sub):
+        buf[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + len(subs[s][2])] = subs[s][2]
+    if mutate:
+        mutate(buf, desc)
+    t_desc = torch.from_numpy(desc.view(np.uint8).copy()).cuda()
+    t_buf = torch.from_numpy(buf).cuda()
+    t_first = torch.from_numpy(tile_first.view(np.int32).copy()).cuda()
+    t_tu = torch.from_numpy(tus.view(np.uint8).reshape(-1).copy()).cuda()
+    t_co = torch.full((max(off, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    t_res = torch.full((2 * n_sub,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.residual_parse_device(n_sub, t_desc.data_ptr(), t_buf.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(), t_co.data_ptr(), t_res.data_ptr())
+    hip.synchronize()
+    co = t_co.cpu().numpy()
+    res = t_res.cpu().numpy().view(H.RESULT_DTYPE)
+    out, o = [], 0
+    for s in subs:
+        blocks = []
+        for (w, h, _, _) in s[0]:
+            blocks.append(co[o:o + w * h].reshape(h, w))
+            o += w * h
+        out.append(blocks)
+    return out, res
+
+
+@pytest.mark.parametrize("flags", [0, H.TU_DEP_QUANT])
+def test_parse_gives_the_coded_blocks_back(hip, flags):
+    """Without sign hiding decode(encode(block)) == block: every shape, several blocks per substream, ragged substreams."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(0x9A + flags)
+    n_sub = 150
+    qps = rng.integers(0, 64, n_sub)
+    subs = build(rng, n_sub, lambda s: flags, qps)
+    got, res = parse(hip, subs, qps)
+    assert not res["flags"].any()
+    for s, (metas, blocks, data) in enumerate(subs):
+        rc, want, nbits = orc.residual_decode(data, int(qps[s]), metas)
+        assert rc == 0 and int(res["n_bits"][s]) == nbits, s
+        for k, c in enumerate(blocks):
+            w, h = metas[k][0], metas[k][1]
+            we, he = min(w, 32), min(h, 32)
+            assert np.array_equal(got[s][k][:he, :we], c[:he, :we]), (s, k, c.shape)       # the coded region comes back
+            assert np.array_equal(got[s][k][:he, :we], want[k][:he, :we]), (s, k)
+
+
+def test_parse_with_sign_hiding_matches_the_oracle(hip):
+    orc = H.load_oracle()
+    rng = np.random.default_rng(0x51)
+    n_sub = 80
+    qps = rng.integers(20, 40, n_sub)
+    subs = build(rng, n_sub, lambda s: H.TU_SIGN_HIDING | (H.TU_DEP_QUANT if s & 1 else 0), qps)
+    got, res = parse(hip, subs, qps)
+    assert not res["flags"].any()
+    for s, (metas, blocks, data) in enumerate(subs):
+        rc, want, nbits = orc.residual_decode(data, int(qps[s]), metas)
+        assert rc == 0 and int(res["n_bits"][s]) == nbits
+        for k in range(len(blocks)):
+            we, he = min(metas[k][0], 32), min(metas[k][1], 32)
+            assert np.array_equal(got[s][k][:he, :we], want[k][:he, :we]), (s, k)
+
+
+def test_parse_error_flags(hip):
+    rng = np.random.default_rng(3)
+    qps = np.full(6, 30)
+    subs = build(rng, 6, lambda s: 0, qps, max_blocks=4)
+    # 0: intact; 1: truncated input; 2: stop pattern destroyed; 3: a transform-skip block (not covered); 4, 5: intact
+    caps = [len(s[2]) for s in subs]
+    caps[1] = max(1, caps[1] // 3)
+    subs[3] = ([(m[0], m[1], m[2], H.TU_TRANSFORM_SKIP) if i == 0 else m for i, m in enumerate(subs[3][0])], subs[3][1], subs[3][2])
+
+    def mutate(buf, desc):
+        o = int(desc["byte_offset"][2]) + len(subs[2][2]) - 1
+        buf[o] = 0x00 if buf[o] != 0 else 0x55
+
+    got, res = parse(hip, subs, qps, capacities=caps, mutate=mutate)
+    assert int(res["flags"][0]) == 0 and int(res["flags"][4]) == 0 and int(res["flags"][5]) == 0
+    assert int(res["flags"][1]) & H.RES_UNDERRUN
+    assert int(res["flags"][2]) & H.RES_BAD_STOP
+    assert int(res["flags"][3]) & H.RES_BAD_RECORD
+    for s in (0, 4, 5):
+        for k, c in enumerate(subs[s][1]):
+            we, he = min(c.shape[1], 32), min(c.shape[0], 32)
+            assert np.array_equal(got[s][k][:he, :we], c[:he, :we])
