@@ -176,6 +176,22 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
                   and bool(torch.equal(t_bins, (t_rec < 0).to(torch.uint8))))
     ok = ok and round_trip
     out_bytes = int(((res["n_bits"].astype(np.int64) + 7) // 8).sum())
+    # ... and back: the residual parser turns the bytes into coefficient blocks again, deriving every context itself.
+    # The workload codes with sign-data hiding, which leaves one sign per group to the parity of the level sum (an
+    # encoder's quantiser arranges that; random blocks do not), so the magnitudes are what must come back exactly.
+    t_first = (torch.arange(n_tiles + 1, device="cuda", dtype=torch.int32) * per_tile).contiguous()
+    t_dec = torch.zeros_like(t_co)
+    t_res_p = torch.zeros(2 * n_tiles, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    hip.profile_enable(3)
+    for _ in range(3):
+        hip.residual_parse_device(n_tiles, t_ddesc.data_ptr(), t_bytes.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(),
+                                  t_dec.data_ptr(), t_res_p.data_ptr())
+    parse_ms = float(np.mean([ms for kk, ms in hip.profile_read() if kk == 9][1:]))
+    res_p = t_res_p.cpu().numpy().view(capi.RESULT_DTYPE)
+    parsed_back = (not res_p["flags"].any() and bool(np.array_equal(res_p["n_bits"], t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)["n_bits"]))
+                   and bool(torch.equal(t_dec.abs(), t_co.abs())))
+    ok = ok and parsed_back
     n_coef = c_u * copies
     bytes1 = 4 * n_coef + (16 + 4 + 4) * n
     bytes2 = 4 * n_coef + 2 * n_bins + (16 + 8 + 4 + 4) * n
@@ -192,6 +208,10 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
             # the same records through the bin encoder (one substream per tile, TRM-terminated), decoded back
             "to_bytes": {"encode_kernel_ms": round(enc, 4), "coefficients_to_bytes_ms": round(p1 + p2 + enc, 4),
                          "bitstream_bytes": out_bytes, "round_trip": bool(round_trip)},
+            # bytes -> coefficients by the residual parser (contexts derived on the device, nothing supplied but block sizes)
+            "parse": {"kernel": "residual_parse_kernel", "kernel_ms": round(parse_ms, 4),
+                      "mbins_s": round(n_bins / (parse_ms * 1e-3) / 1e6, 1), "mcoeff_s": round(n_coef / (parse_ms * 1e-3) / 1e6, 1),
+                      "magnitudes_match": bool(parsed_back)},
             "records_match_reference": bool(ok)}
 
 
