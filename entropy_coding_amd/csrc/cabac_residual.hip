@@ -776,12 +776,44 @@ struct ParseDec {  // BinDecoderBase state
   int32_t bits_needed;
   const uint8_t *src;
   uint32_t pos, cap, underrun;
+  // the input is consumed 16 bytes at a time: the current chunk and the next one (loaded a chunk ahead, so that the
+  // serial walk never waits for memory) live in registers
+  uint64_t cur_lo, cur_hi, nxt_lo, nxt_hi;
+  uint32_t chunk;  // byte position of the current chunk
 };
 
+// bytes [at, at + 16) of the substream; beyond byte_capacity reads as zero, never touching memory there
+__device__ __forceinline__ void pd_load16(const ParseDec &d, uint32_t at, uint64_t &lo, uint64_t &hi) {
+  if (at + 16u <= d.cap && (reinterpret_cast<uintptr_t>(d.src) & 15u) == 0u) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(d.src + at);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  } else {
+    lo = hi = 0;
+    for (uint32_t i = 0; i < 16u; i++) {
+      const uint64_t b = at + i < d.cap ? d.src[at + i] : 0u;
+      if (i < 8u) lo |= b << (8u * i);
+      else hi |= b << (8u * (i - 8u));
+    }
+  }
+}
+
+__device__ __forceinline__ void pd_open(ParseDec &d) {
+  d.chunk = 0;
+  pd_load16(d, 0u, d.cur_lo, d.cur_hi);
+  pd_load16(d, 16u, d.nxt_lo, d.nxt_hi);
+}
+
 __device__ __forceinline__ uint32_t pd_byte(ParseDec &d) {  // InputBitstream::readByte, bit_stream.cpp:268-274
-  uint32_t b = 0;
-  if (d.pos < d.cap) b = d.src[d.pos];
-  else d.underrun = 1;
+  if (d.pos >= d.chunk + 16u) {
+    d.cur_lo = d.nxt_lo;
+    d.cur_hi = d.nxt_hi;
+    d.chunk += 16u;
+    pd_load16(d, d.chunk + 16u, d.nxt_lo, d.nxt_hi);
+  }
+  const uint32_t i = d.pos - d.chunk;
+  const uint32_t b = (uint32_t)((i < 8u ? d.cur_lo >> (8u * i) : d.cur_hi >> (8u * (i - 8u))) & 0xffu);
+  if (d.pos >= d.cap) d.underrun = 1;
   d.pos++;
   return b;
 }
@@ -872,7 +904,10 @@ __global__ __launch_bounds__(64) void residual_parse_kernel(uint32_t n_sub, cons
   dec.range = 510u;  // BinDecoderBase::start, arith_codec.cpp:60-66
   dec.value = 0;
   dec.bits_needed = -8;
+  dec.cur_lo = dec.cur_hi = dec.nxt_lo = dec.nxt_hi = 0;
+  dec.chunk = 0;
   if (lane == 0u) {
+    pd_open(dec);
     dec.value = pd_byte(dec) << 8;
     dec.value += pd_byte(dec);
   }
