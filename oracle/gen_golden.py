@@ -183,9 +183,46 @@ def residual(ref):
                    "n_blocks": k, "n_records": total, "records_md5": md5.hexdigest()}, f, indent=1)
 
 
+def residual_parse(ref):
+    """(g) residual parser: substreams of several blocks -> the coefficients the reference's CABACReader::residual_coding
+    decodes (ref_residual_decode in oracle/ref_harness.cpp).  The bytes come from the reference's own writer
+    (residual_coding on BinEncoder_Std via the recording harness + encode).  tests/golden/residual_parse.npz"""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(0x9A45E)
+    shapes = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
+    out = {}
+    n_sub = 24
+    for s in range(n_sub):
+        flags = [0, H.TU_DEP_QUANT, H.TU_SIGN_HIDING, H.TU_DEP_QUANT | H.TU_SIGN_HIDING][s % 4]
+        qp = int(rng.integers(0, 64))
+        metas, blocks, recs = [], [], []
+        for k in range(int(rng.integers(2, 12))):
+            w, h = shapes[int(rng.integers(0, len(shapes)))]
+            c = H.random_block(rng, w, h, density=float(rng.choice([0.05, 0.3, 0.7, 1.0])), big=float(rng.choice([0.0, 0.05, 0.3])),
+                               huge=0.02 if rng.random() < 0.1 else 0.0, last_frac=float(rng.choice([1.0, 0.5, 0.2])))
+            ch = int(rng.integers(0, 2))
+            metas.append((w, h, ch, flags))
+            blocks.append(c)
+            recs.append(ref.residual_records(c, ch, flags)[0])
+        rec = np.concatenate(recs + [np.array([0x81FF], np.uint16)])
+        data, _ = ref.encode_records(rec, qp, 2, 3)
+        rc, dec, nbits = ref.residual_decode(data, qp, metas)
+        assert rc == 0
+        out["s%d_meta" % s] = np.array(metas, np.int32)
+        out["s%d_qp" % s] = np.array([qp, nbits], np.int64)
+        out["s%d_bytes" % s] = data
+        out["s%d_coeff" % s] = np.concatenate([d.ravel() for d in dec]).astype(np.int32)
+    out["n_sub"] = np.array([n_sub], np.int32)
+    path = os.path.join(GOLD, "residual_parse.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "residual":
         residual(H.load_ref())
+        residual_parse(H.load_ref())
     else:
         main()
         residual(H.load_ref())
+        residual_parse(H.load_ref())

@@ -137,3 +137,27 @@ def test_parse_error_flags(hip):
         for k, c in enumerate(subs[s][1]):
             we, he = min(c.shape[1], 32), min(c.shape[0], 32)
             assert np.array_equal(got[s][k][:he, :we], c[:he, :we])
+
+
+def test_golden_substreams_from_the_reference_reader(hip):
+    """bytes coded by the reference's writer -> the coefficients its reader decodes (tests/golden/residual_parse.npz)."""
+    import os
+    g = np.load(os.path.join(H.GOLDEN, "residual_parse.npz"))
+    n_sub = int(g["n_sub"][0])
+    subs, qps = [], []
+    for s in range(n_sub):
+        metas = [tuple(int(x) for x in m) for m in g["s%d_meta" % s]]
+        co = g["s%d_coeff" % s]
+        blocks, o = [], 0
+        for (w, h, _, _) in metas:
+            blocks.append(co[o:o + w * h].reshape(h, w))
+            o += w * h
+        subs.append((metas, blocks, g["s%d_bytes" % s]))
+        qps.append(int(g["s%d_qp" % s][0]))
+    got, res = parse(hip, subs, np.array(qps))
+    assert not res["flags"].any()
+    for s in range(n_sub):
+        assert int(res["n_bits"][s]) == int(g["s%d_qp" % s][1])
+        for k, c in enumerate(subs[s][1]):
+            we, he = min(c.shape[1], 32), min(c.shape[0], 32)
+            assert np.array_equal(got[s][k][:he, :we], c[:he, :we]), (s, k)

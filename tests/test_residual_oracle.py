@@ -201,3 +201,15 @@ def test_residual_parser_errors():
     assert rc == 0 and np.array_equal(got[0], c)
     assert orc.residual_decode(data[:1], 32, [(4, 4, 0, 0)])[0] == -4                 # read past the end
     assert orc.residual_decode(data, 32, [(4, 4, 0, H.TU_TRANSFORM_SKIP)])[0] == -2   # not covered by the parser
+
+
+def test_golden_parse_substreams():
+    """The oracle's parser against what the compiled reference reader decoded (tests/golden/residual_parse.npz)."""
+    orc = H.load_oracle()
+    g = np.load(os.path.join(H.GOLDEN, "residual_parse.npz"))
+    for s in range(int(g["n_sub"][0])):
+        metas = [tuple(int(x) for x in m) for m in g["s%d_meta" % s]]
+        qp, nbits = [int(x) for x in g["s%d_qp" % s]]
+        rc, dec, nb = orc.residual_decode(g["s%d_bytes" % s], qp, metas)
+        assert rc == 0 and nb == nbits
+        assert np.array_equal(np.concatenate([d.ravel() for d in dec]), g["s%d_coeff" % s]), s
