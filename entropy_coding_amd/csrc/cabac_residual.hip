@@ -790,7 +790,8 @@ __device__ __forceinline__ void pd_load16(const ParseDec &d, uint32_t at, uint64
     hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
   } else {
     lo = hi = 0;
-    for (uint32_t i = 0; i < 16u; i++) {
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16u; i++) {  // the tail of the substream (or an unaligned buffer): rare, keep it small
       const uint64_t b = at + i < d.cap ? d.src[at + i] : 0u;
       if (i < 8u) lo |= b << (8u * i);
       else hi |= b << (8u * (i - 8u));
