@@ -28,7 +28,7 @@ EXPORTS = [
     "cabac_hip_encode_bound", "cabac_hip_init", "cabac_hip_destroy", "cabac_hip_strerror",
     "cabac_hip_last_error", "cabac_hip_set_stream", "cabac_hip_synchronize", "cabac_hip_set_variant",
     "cabac_hip_encode_device", "cabac_hip_decode_device", "cabac_hip_ctx_init_device",
-    "cabac_hip_binarize_device", "cabac_hip_residual_device", "cabac_hip_residual_batch", "cabac_hip_residual_parse_device", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
+    "cabac_hip_binarize_device", "cabac_hip_residual_device", "cabac_hip_residual_batch", "cabac_hip_residual_parse_device", "cabac_hip_residual_parse_batch", "cabac_hip_encode_batch", "cabac_hip_decode_batch",
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
@@ -70,6 +70,7 @@ def load_library():
     L.cabac_hip_binarize_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_parse_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.cabac_hip_residual_parse_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp]
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
@@ -223,6 +224,20 @@ class CabacHip:
         """cabac_hip_residual_parse_device: bytes -> coefficient blocks, contexts derived on the device."""
         self._check(self.L.cabac_hip_residual_parse_device(self.h, n_sub, vp(d_desc), vp(d_bytes), vp(d_tile_first), vp(d_tu),
                                                            vp(d_coeff), vp(d_results)))
+
+    def residual_parse_batch(self, desc, data, tile_first, tus, n_coeff_total, check=True):
+        """Host arrays in, (coeff, results) out (cabac_hip_residual_parse_batch, synchronous)."""
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        data = np.ascontiguousarray(data, np.uint8)
+        tile_first = np.ascontiguousarray(tile_first, np.uint32)
+        tus = np.ascontiguousarray(tus, TU_DTYPE)
+        coeff = np.zeros(max(int(n_coeff_total), 1), np.int32)
+        res = np.zeros(max(len(desc), 1), RESULT_DTYPE)
+        rc = self.L.cabac_hip_residual_parse_batch(self.h, len(desc), desc.ctypes.data, data.ctypes.data, len(data),
+                                                   tile_first.ctypes.data, tus.ctypes.data, coeff.ctypes.data, int(n_coeff_total),
+                                                   res.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return coeff[: int(n_coeff_total)], res[: len(desc)]
 
     def residual_batch(self, tus, coeff, check=True):
         """Host arrays in, (records, offsets, info) out (cabac_hip_residual_batch: both passes, synchronous)."""

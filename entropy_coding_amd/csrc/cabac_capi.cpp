@@ -528,4 +528,52 @@ int cabac_hip_residual_parse_device(cabac_hip_ctx *c, uint32_t n_sub, const caba
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                   uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
+                                   uint64_t n_coeff_total, cabac_substream_result *results) {
+  if (!c || (n_sub && (!desc || !bytes || !tile_first || !tus || !coeff || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (n_sub == 0) return CABAC_HIP_OK;
+  const uint32_t n_tu = tile_first[n_sub];
+  for (uint32_t s = 0; s < n_sub; s++) {
+    if (tile_first[s] > tile_first[s + 1]) return fail(c, CABAC_HIP_ERR_INVALID, "tile_first must not decrease");
+    if (desc[s].byte_offset > bytes_total || desc[s].byte_capacity > bytes_total - desc[s].byte_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "bytes out of range");
+    if ((desc[s].init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
+  }
+  for (uint32_t t = 0; t < n_tu; t++) {
+    if (tus[t].log2_width > 6 || tus[t].log2_height > 6) continue;  // flagged by the kernel, writes nothing
+    const uint64_t n = uint64_t(1) << (tus[t].log2_width + tus[t].log2_height);
+    if (tus[t].coeff_offset > n_coeff_total || n > n_coeff_total - tus[t].coeff_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "coefficients out of range");
+  }
+  DeviceGuard g(c->device);
+  int rc;
+  // staging: [0] substream descriptors, [2] bytes, [3] tile_first then block descriptors, [1] coefficients, [4] results
+  const size_t first_bytes = (size_t(n_sub) + 1) * sizeof(uint32_t), first_pad = (first_bytes + 15) / 16 * 16;
+  if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, 2, bytes_total))) return rc;
+  if ((rc = ensure(c, 3, first_pad + size_t(n_tu) * sizeof(cabac_tu_desc)))) return rc;
+  if ((rc = ensure(c, 1, n_coeff_total * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, 4, n_sub * sizeof(cabac_substream_result)))) return rc;
+  uint8_t *d_first = static_cast<uint8_t *>(c->d_buf[3]);
+  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
+  if (bytes_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[2], bytes, bytes_total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_first, tile_first, first_bytes, hipMemcpyHostToDevice, c->stream));
+  if (n_tu) HIP_TRY(c, hipMemcpyAsync(d_first + first_pad, tus, size_t(n_tu) * sizeof(cabac_tu_desc), hipMemcpyHostToDevice, c->stream));
+  // what the parser does not write (outside the coded region of 64-wide blocks) keeps the caller's values
+  if (n_coeff_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], coeff, n_coeff_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  rc = cabac_hip_residual_parse_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint8_t *)c->d_buf[2],
+                                       (const uint32_t *)d_first, (const cabac_tu_desc *)(d_first + first_pad),
+                                       (int32_t *)c->d_buf[1], (cabac_substream_result *)c->d_buf[4]);
+  if (rc) return rc;
+  if (n_coeff_total) HIP_TRY(c, hipMemcpyAsync(coeff, c->d_buf[1], n_coeff_total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[4], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int status = CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++)
+    if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+  if (status) c->last_error = "substream flag set (see results[].flags)";
+  return status;
+}
+
 }  // extern "C"

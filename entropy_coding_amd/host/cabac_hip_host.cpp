@@ -227,6 +227,66 @@ HipBatch::ResidualResult HipBatch::residual(const std::vector<ResidualBlock> &bl
   return r;
 }
 
+std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<ParseJob> &jobs) {
+  const uint32_t n = uint32_t(jobs.size());
+  std::vector<std::vector<int32_t>> out(n);
+  if (n == 0) return out;
+  std::vector<cabac_substream_desc> desc(n);
+  std::vector<uint32_t> first(size_t(n) + 1, 0);
+  std::vector<cabac_tu_desc> tus;
+  uint64_t byte_total = 0, coeff_total = 0;
+  for (uint32_t s = 0; s < n; s++) {
+    desc[s] = cabac_substream_desc{};
+    desc[s].byte_offset = byte_total;
+    desc[s].byte_capacity = jobs[s].n_bytes;
+    desc[s].qp = jobs[s].qp;
+    desc[s].init_id = uint32_t(jobs[s].initId) | CABAC_SUB_FINISH;
+    byte_total += (uint64_t(jobs[s].n_bytes) + 15) / 16 * 16;
+    for (const ResidualBlock &b : jobs[s].blocks) {
+      unsigned lw = 0, lh = 0;
+      while ((1u << lw) < b.width) lw++;
+      while ((1u << lh) < b.height) lh++;
+      if ((1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6 || b.transformSkip)
+        throw Exception("residualParse: power-of-two blocks up to 64, regular residual coding only");
+      cabac_tu_desc t{};
+      t.coeff_offset = coeff_total;
+      t.log2_width = uint8_t(lw);
+      t.log2_height = uint8_t(lh);
+      t.channel = b.chroma ? 1 : 0;
+      t.flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
+                        (b.tsFlag ? CABAC_TU_TS_FLAG : 0u));
+      t.max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
+      tus.push_back(t);
+      coeff_total += uint64_t(b.width) * b.height;
+    }
+    first[s + 1] = uint32_t(tus.size());
+  }
+  std::vector<uint8_t> bytes(byte_total ? byte_total : 16, 0);
+  for (uint32_t s = 0; s < n; s++)
+    if (jobs[s].n_bytes) std::memcpy(bytes.data() + desc[s].byte_offset, jobs[s].bytes, jobs[s].n_bytes);
+  std::vector<int32_t> coeff(coeff_total ? coeff_total : 1, 0);
+  std::vector<cabac_substream_result> res(n);
+  if (tus.empty()) tus.push_back(cabac_tu_desc{});
+  const int rc = cabac_hip_residual_parse_batch(handle(), n, desc.data(), bytes.data(), bytes.size(), first.data(), tus.data(),
+                                                coeff.data(), coeff_total, res.data());
+  if (rc == CABAC_HIP_ERR_SUBSTREAM) {
+    for (uint32_t s = 0; s < n; s++) {
+      if (res[s].flags & CABAC_RES_UNDERRUN) throw Exception("FIFO exceeded");
+      if (res[s].flags & CABAC_RES_BAD_STOP) throw Exception("No proper stop/alignment pattern at end of CABAC stream.");
+      if (res[s].flags) throw Exception("residualParse: block not covered by the parser");
+    }
+  }
+  check_status(m_ctx, rc, "cabac_hip_residual_parse_batch");
+  uint64_t at = 0;
+  for (uint32_t s = 0; s < n; s++) {
+    uint64_t len = 0;
+    for (const ResidualBlock &b : jobs[s].blocks) len += uint64_t(b.width) * b.height;
+    out[s].assign(coeff.begin() + at, coeff.begin() + at + len);
+    at += len;
+  }
+  return out;
+}
+
 void HipBatch::decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
                       std::vector<uint32_t> *bitsRead) {
   const uint32_t n = uint32_t(jobs.size());

@@ -157,6 +157,19 @@ public:
   };
   ResidualResult residual(const std::vector<ResidualBlock> &blocks);
 
+  // Residual parser (CABACReader::residual_coding, cabac_reader.cpp:2647-3128): the blocks of each substream decoded from
+  // its bytes, every context derived on the device.  blocks[i] gives the geometry (coeff is ignored); the result holds the
+  // blocks of all substreams back to back (width * height each).  Throws Exception like the reference's CHECKs on a
+  // substream that runs out of bytes or misses its terminate bin / stop pattern.
+  struct ParseJob {
+    const uint8_t *bytes;
+    uint32_t n_bytes;
+    int qp;
+    int initId;
+    std::vector<ResidualBlock> blocks;
+  };
+  std::vector<std::vector<int32_t>> residualParse(const std::vector<ParseJob> &jobs);
+
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
   // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned

@@ -314,6 +314,12 @@ int cabac_hip_residual_parse_device(cabac_hip_ctx *ctx, uint32_t n_sub, const ca
                                     const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
                                     int32_t *d_coeff, cabac_substream_result *d_results);
 
+/* Host-pointer form of cabac_hip_residual_parse_device (synchronous).  bytes_total / n_coeff_total bound the two
+ * buffers; coeff receives the blocks at tus[t].coeff_offset.  Returns CABAC_HIP_ERR_SUBSTREAM if any result flag is set. */
+int cabac_hip_residual_parse_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                   uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus,
+                                   int32_t *coeff, uint64_t n_coeff_total, cabac_substream_result *results);
+
 /* Host-pointer form of cabac_hip_residual_device (synchronous, both passes).  `offsets` receives n_tu + 1 record
  * offsets (block t's records are records[offsets[t] .. offsets[t+1])); n_records/info as on the device, info may
  * be NULL.  If `records` is NULL or records_capacity is less than offsets[n_tu], only the sizes are produced

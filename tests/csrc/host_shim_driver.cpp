@@ -197,4 +197,67 @@ int shim_estimate_many(const uint16_t *records, const long *rec_off, int n, cons
   }
 }
 
+// residual coding through the host shim: HipBatch::residual (blocks -> records), the records coded by BinEncoderHip
+// into one substream per job, HipBatch::residualParse (bytes -> blocks).  geom = {w, h, chroma, flags} per block;
+// job j holds blocks [job_first[j], job_first[j+1]).  coeff_out receives the parsed blocks back to back.
+int shim_residual_round_trip(int n_jobs, const int *job_first, const int *geom, const int32_t *coeff_in, int qp,
+                             int32_t *coeff_out, long *n_bytes_out) {
+  try {
+    HipBatch batch(0);
+    std::vector<HipBatch::ParseJob> jobs(n_jobs);
+    std::vector<OutputBitstream> streams(n_jobs);
+    std::vector<std::vector<uint8_t>> bytes(n_jobs);
+    const int32_t *cin = coeff_in;
+    for (int j = 0; j < n_jobs; j++) {
+      std::vector<HipBatch::ResidualBlock> blocks;
+      for (int b = job_first[j]; b < job_first[j + 1]; b++) {
+        HipBatch::ResidualBlock r{};
+        r.coeff = cin;
+        r.width = unsigned(geom[4 * b]);
+        r.height = unsigned(geom[4 * b + 1]);
+        r.chroma = geom[4 * b + 2] != 0;
+        r.depQuant = (geom[4 * b + 3] & CABAC_TU_DEP_QUANT) != 0;
+        r.signHiding = (geom[4 * b + 3] & CABAC_TU_SIGN_HIDING) != 0;
+        r.tsFlag = false;
+        r.maxLog2TrDynamicRange = 15;
+        blocks.push_back(r);
+        cin += r.width * r.height;
+      }
+      const HipBatch::ResidualResult rr = batch.residual(blocks);
+      BinEncoderHip enc(batch);
+      enc.init(&streams[j]);
+      enc.reset(qp, 2);
+      for (uint16_t rec : rr.records) {
+        if ((rec & CABAC_REC_ID_MASK) == CABAC_REC_EP) enc.encodeBinEP(rec >> 15);
+        else enc.encodeBin(rec >> 15, rec & CABAC_REC_ID_MASK);
+      }
+      enc.encodeBinTrm(1);
+      enc.finish();
+      jobs[j].qp = qp;
+      jobs[j].initId = 2;
+      jobs[j].blocks = blocks;
+    }
+    batch.flush();
+    long total = 0;
+    for (int j = 0; j < n_jobs; j++) {
+      streams[j].writeByteAlignment();
+      bytes[j] = streams[j].getFIFO();
+      jobs[j].bytes = bytes[j].data();
+      jobs[j].n_bytes = uint32_t(bytes[j].size());
+      total += long(bytes[j].size());
+    }
+    const std::vector<std::vector<int32_t>> out = batch.residualParse(jobs);
+    int32_t *o = coeff_out;
+    for (const auto &v : out) {
+      std::memcpy(o, v.data(), v.size() * sizeof(int32_t));
+      o += v.size();
+    }
+    *n_bytes_out = total;
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 } // extern "C"

@@ -161,3 +161,42 @@ def test_golden_substreams_from_the_reference_reader(hip):
         for k, c in enumerate(subs[s][1]):
             we, he = min(c.shape[1], 32), min(c.shape[0], 32)
             assert np.array_equal(got[s][k][:he, :we], c[:he, :we]), (s, k)
+
+
+def test_host_pointer_parse_batch(hip):
+    """cabac_hip_residual_parse_batch (host arrays, staging inside) gives the coded blocks back; a truncated substream is
+    reported through the status and the flags."""
+    rng = np.random.default_rng(21)
+    qps = rng.integers(10, 50, 12)
+    subs = build(rng, 12, lambda s: H.TU_DEP_QUANT if s & 1 else 0, qps, max_blocks=6)
+    metas = [m for s in subs for m in s[0]]
+    tus = np.zeros(len(metas), H.TU_DTYPE)
+    off = 0
+    for i, (w, h, ch, fl) in enumerate(metas):
+        tus[i]["coeff_offset"], tus[i]["log2_width"], tus[i]["log2_height"], tus[i]["channel"], tus[i]["flags"] = off, int(np.log2(w)), int(np.log2(h)), ch, fl
+        off += w * h
+    first = np.concatenate([[0], np.cumsum([len(s[0]) for s in subs])]).astype(np.uint32)
+    desc = np.zeros(len(subs), H.DESC_DTYPE)
+    slots = (np.array([len(s[2]) for s in subs], np.uint64) + 15) // 16 * 16
+    desc["byte_offset"] = np.concatenate([[0], np.cumsum(slots)[:-1]])
+    desc["byte_capacity"] = [len(s[2]) for s in subs]
+    desc["qp"] = qps
+    desc["init_id"] = 2 | H.SUB_FINISH
+    buf = np.zeros(int(slots.sum()), np.uint8)
+    for s in range(len(subs)):
+        buf[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + len(subs[s][2])] = subs[s][2]
+    co, res = hip.residual_parse_batch(desc, buf, first, tus, off)
+    assert not res["flags"].any()
+    o = 0
+    for s in subs:
+        for c in s[1]:
+            h, w = c.shape
+            got = co[o:o + w * h].reshape(h, w)
+            assert np.array_equal(got[:min(h, 32), :min(w, 32)], c[:min(h, 32), :min(w, 32)])
+            o += w * h
+    bad = desc.copy()
+    bad["byte_capacity"][3] = 2
+    with pytest.raises(capi.CabacHipError):
+        hip.residual_parse_batch(bad, buf, first, tus, off)
+    co2, res2 = hip.residual_parse_batch(bad, buf, first, tus, off, check=False)
+    assert int(res2["flags"][3]) & H.RES_UNDERRUN and not res2["flags"][[0, 1, 2, 4]].any()

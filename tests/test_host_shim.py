@@ -244,3 +244,33 @@ def test_estimator_shim_on_gpu(drv):
     assert rc == 0, drv.shim_last_error()
     for i in range(50):
         assert orc.estimate_records(recs[i], int(qps[i]), int(ids[i])) == (0, int(out[i]))
+
+
+@pytest.mark.gpu
+def test_residual_round_trip_through_the_shim(drv):
+    """HipBatch::residual -> BinEncoderHip -> HipBatch::residualParse: coefficient blocks to bytes and back, C++ only."""
+    rng = np.random.default_rng(77)
+    blocks, geom, first = [], [], [0]
+    for j in range(5):
+        for k in range(int(rng.integers(1, 7))):
+            w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (2, 8), (64, 64)][int(rng.integers(0, 7))]
+            blocks.append(H.random_block(rng, w, h, density=0.5, big=0.1))
+            geom.append((w, h, int(rng.integers(0, 2)), H.TU_DEP_QUANT if j & 1 else 0))
+        first.append(len(blocks))
+    cin = np.concatenate([b.ravel() for b in blocks]).astype(np.int32)
+    cout = np.zeros_like(cin)
+    g = np.array(geom, np.int32).ravel()
+    f = np.array(first, np.int32)
+    nb = ctypes.c_long(0)
+    i32p, ip = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)
+    drv.shim_residual_round_trip.argtypes = [ctypes.c_int, ip, ip, i32p, ctypes.c_int, i32p, ctypes.POINTER(ctypes.c_long)]
+    rc = drv.shim_residual_round_trip(5, f.ctypes.data_as(ip), g.ctypes.data_as(ip), cin.ctypes.data_as(i32p), 30,
+                                      cout.ctypes.data_as(i32p), ctypes.byref(nb))
+    assert rc == 0, drv.shim_last_error()
+    o = 0
+    for b in blocks:
+        h, w = b.shape
+        got = cout[o:o + w * h].reshape(h, w)
+        assert np.array_equal(got[:min(h, 32), :min(w, 32)], b[:min(h, 32), :min(w, 32)])
+        o += w * h
+    assert nb.value > 0
