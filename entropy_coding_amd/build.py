@@ -1,7 +1,11 @@
-"""hipcc build driver for libcabac_hip.so (gfx950 only, in-tree so that the .so travels to the GPU box)."""
+"""hipcc build driver for libcabac_hip.so (gfx950 only, in-tree so that the .so travels to the GPU box).
+
+Every source is compiled to its own object under build/ (git-ignored, gpurun-ignored), in parallel, and only when it
+or a header changed; the objects are then linked into the in-tree library."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
@@ -9,6 +13,8 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libcabac_hip.so")
+OBJ = os.path.join(ROOT, "build", "obj")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-I" + HOST]
 
 
 def library_path():
@@ -25,19 +31,19 @@ def _sources():
     return srcs
 
 
-def _deps():
-    deps = list(_sources())
+def _headers():
+    hdr = []
     for d in (CSRC, HOST, INCLUDE):
         if os.path.isdir(d):
-            deps += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
-    return deps
+            hdr += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
+    return hdr
 
 
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    return any(os.path.getmtime(p) > t for p in _sources() + _headers())
 
 
 def build_library(force=False, verbose=False):
@@ -49,14 +55,27 @@ def build_library(force=False, verbose=False):
         if os.path.exists(LIB):
             return LIB  # e.g. a box without the toolchain: use the prebuilt in-tree library
         raise RuntimeError("hipcc not found and no prebuilt libcabac_hip.so")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC, "-I" + HOST] + _sources() + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    newest_header = max([os.path.getmtime(p) for p in _headers()] + [os.path.getmtime(__file__)])
+    jobs = []
+    for src in _sources():
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, os.path.basename(s) + ".o") for s in _sources()]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

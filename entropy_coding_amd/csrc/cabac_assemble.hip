@@ -14,7 +14,10 @@
 namespace cabac {
 
 // exclusive scan of the substream sizes: one workgroup, tiles of 1024 with a running carry
-__global__ __launch_bounds__(1024) void sizes_scan_kernel(uint32_t n_sub, const cabac_substream_result *__restrict__ results,
+// (a substream whose encode overflowed its slot — CABAC_RES_OVERFLOW — counts on past byte_capacity; only what the slot
+// holds is assembled)
+__global__ __launch_bounds__(1024) void sizes_scan_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                          const cabac_substream_result *__restrict__ results,
                                                           uint64_t *__restrict__ offsets) {
   __shared__ uint64_t wave_sum[16];
   __shared__ uint64_t carry;
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(1024) void sizes_scan_kernel(uint32_t n_sub, const 
   __syncthreads();
   for (uint32_t tile = 0; tile < n_sub; tile += 1024) {
     const uint32_t s = tile + tid;
-    const uint64_t sz = s < n_sub ? (uint64_t)((results[s].n_bits + 7u) >> 3) : 0;
+    const uint64_t sz = s < n_sub ? (uint64_t)min((results[s].n_bits + 7u) >> 3, desc[s].byte_capacity) : 0;
     uint64_t incl = sz;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void count_emulations_kernel(uint32_t n_sub, c
   const uint8_t *p = bytes + desc[s].byte_offset;
   uint32_t n = (results[s].n_bits + 7u) >> 3;  // FIFO bytes (a trailing partial byte counts as held bits in the
   if (results[s].n_bits & 7u) n -= 1;           // reference and is not part of the FIFO)
+  n = min(n, desc[s].byte_capacity);            // an overflowed encode counts on past its slot
   uint32_t cnt = 0, carry = 0;                  // carry: length of the zero run that ends at the last byte seen
   for (uint32_t base = 0; base < n; base += 64u) {
     const uint32_t i = base + lane;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void count_emulations_kernel(uint32_t n_sub, c
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,
                            uint64_t payload_capacity, uint64_t *offsets) {
-  hipLaunchKernelGGL(sizes_scan_kernel, dim3(1), dim3(1024), 0, st, n_sub, results, offsets);
+  hipLaunchKernelGGL(sizes_scan_kernel, dim3(1), dim3(1024), 0, st, n_sub, desc, results, offsets);
   if (n_sub)
     hipLaunchKernelGGL(copy_substreams_kernel<true>, dim3(n_sub), dim3(256), 0, st, n_sub, desc, offsets,
                        const_cast<uint8_t *>(bytes), payload, payload_capacity);

@@ -97,8 +97,10 @@ int check_desc_host(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc
                     uint64_t bytes_total) {
   for (uint32_t s = 0; s < n_sub; s++) {
     const cabac_substream_desc &d = desc[s];
-    if (d.rec_offset + d.n_records > n_records_total) return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
-    if (d.byte_offset + d.byte_capacity > bytes_total) return fail(c, CABAC_HIP_ERR_INVALID, "bytes out of range");
+    if (d.rec_offset > n_records_total || d.n_records > n_records_total - d.rec_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if (d.byte_offset > bytes_total || d.byte_capacity > bytes_total - d.byte_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "bytes out of range");
     if (d.byte_offset & 15u) return fail(c, CABAC_HIP_ERR_INVALID, "byte_offset must be 16-byte aligned");
     if ((d.init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
   }
@@ -375,7 +377,8 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
   if (!c || (n_sub && (!desc || !frac_bits))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   if (n_sub == 0) return CABAC_HIP_OK;
   for (uint32_t s = 0; s < n_sub; s++) {
-    if (desc[s].rec_offset + desc[s].n_records > n_records_total) return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if (desc[s].rec_offset > n_records_total || desc[s].n_records > n_records_total - desc[s].rec_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
     if ((desc[s].init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
   }
   DeviceGuard g(c->device);

@@ -64,15 +64,28 @@ class InputBitstream {
 public:
   std::vector<uint8_t> m_fifo;
   uint32_t m_fifo_idx = 0;
+  uint32_t m_num_held_bits = 0;  // unread bits of the last byte taken from the FIFO: its low m_num_held_bits bits
+  uint8_t m_held_bits = 0;
+  uint32_t m_numBitsRead = 0;
 
   std::vector<uint8_t> &getFifo() { return m_fifo; }
   const std::vector<uint8_t> &getFifo() const { return m_fifo; }
+  void read(uint32_t uiNumberOfBits, uint32_t &ruiBits);  // bit_stream.cpp:204-268 (throws "Exceeded FIFO size")
+  uint32_t read(uint32_t numberOfBits) {
+    uint32_t v;
+    read(numberOfBits, v);
+    return v;
+  }
   uint32_t readByte();                      // bit_stream.cpp:268-274 (throws "FIFO exceeded")
   void peekPreviousByte(uint32_t &byte);    // :276-279
+  uint32_t readOutTrailingBits();           // :355-364
+  uint32_t readByteAlignment();             // :417-430: the stop bit '1', then zero bits up to the byte boundary
+  uint8_t getHeldBits() const { return m_held_bits; }
   uint32_t getByteLocation() const { return m_fifo_idx; }
-  uint32_t getNumBitsUntilByteAligned() const { return 0; }
-  uint32_t getNumBitsLeft() const { return 8 * (uint32_t(m_fifo.size()) - m_fifo_idx); }
-  InputBitstream *extractSubstream(uint32_t uiNumBits);  // :382-415 (byte-aligned case)
+  uint32_t getNumBitsUntilByteAligned() const { return m_num_held_bits & 7u; }
+  uint32_t getNumBitsLeft() const { return 8 * (uint32_t(m_fifo.size()) - m_fifo_idx) + m_num_held_bits; }
+  uint32_t getNumBitsRead() const { return m_numBitsRead; }
+  InputBitstream *extractSubstream(uint32_t uiNumBits);  // :382-415, any bit position and bit count
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -333,6 +346,8 @@ public:
   unsigned decodeBin(unsigned ctxId);          // :242-277
   unsigned decodeBinEP();                      // :100-114
   unsigned decodeBinsEP(unsigned numBins);     // :116-151
+  unsigned decodeRemAbsEP(unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange);  // :153-179
+  void planRemAbsEP(unsigned value, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange);  // its bypass bins
   unsigned decodeBinTrm();                     // :181-197
   unsigned getNumBitsRead() const { return m_bitsRead; }  // :201-203
 

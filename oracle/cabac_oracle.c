@@ -811,6 +811,83 @@ void orc_decode_batch(const void *desc_, uint32_t first, uint32_t count, const u
   }
 }
 
+/* CPU baseline of bench.py, all host cores: substreams [first, first + count) are encoded and decoded back (bins
+ * checked) by n_threads POSIX threads taking substreams off a shared counter.  out = {bins coded, mismatching or failed
+ * substreams, sum over threads of encode ns, of decode ns}; returns the wall time in ns. */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+typedef struct {
+  const cabac_substream_desc *desc;
+  const uint16_t *records;
+  uint32_t first, count;
+  atomic_uint next;
+  atomic_ullong bins, bad, enc_ns, dec_ns;
+} mt_job;
+
+static uint64_t now_ns(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+static void *mt_worker(void *arg) {
+  mt_job *j = (mt_job *)arg;
+  uint8_t *buf = NULL, *bins = NULL;
+  size_t buf_cap = 0, bins_cap = 0;
+  for (;;) {
+    const uint32_t k = atomic_fetch_add(&j->next, 1u);
+    if (k >= j->count) break;
+    const cabac_substream_desc *d = &j->desc[j->first + k];
+    const uint16_t *rec = j->records + d->rec_offset;
+    const size_t need = (size_t)d->n_records + 64;
+    if (need > buf_cap) { free(buf); buf = (uint8_t *)malloc(buf_cap = need); }
+    if (need > bins_cap) { free(bins); bins = (uint8_t *)malloc(bins_cap = need); }
+    uint32_t nbits = 0, nread = 0;
+    const uint64_t t0 = now_ns();
+    const long nb = orc_encode_records(rec, d->n_records, d->qp, (int)(d->init_id & 3), 3, buf, (long)buf_cap, &nbits);
+    const uint64_t t1 = now_ns();
+    int rc = nb < 0 ? -1 : orc_decode_records(rec, d->n_records, d->qp, (int)(d->init_id & 3), 1, buf, nb, bins, &nread);
+    const uint64_t t2 = now_ns();
+    for (uint32_t i = 0; rc == 0 && i < d->n_records; i++)
+      if (bins[i] != (rec[i] >> 15)) rc = -1;
+    atomic_fetch_add(&j->bins, d->n_records);
+    atomic_fetch_add(&j->enc_ns, t1 - t0);
+    atomic_fetch_add(&j->dec_ns, t2 - t1);
+    if (rc) atomic_fetch_add(&j->bad, 1);
+  }
+  free(buf);
+  free(bins);
+  return NULL;
+}
+
+uint64_t orc_roundtrip_mt(const void *desc, uint32_t first, uint32_t count, const uint16_t *records, int n_threads,
+                          uint64_t *out) {
+  mt_job j;
+  j.desc = (const cabac_substream_desc *)desc;
+  j.records = records;
+  j.first = first;
+  j.count = count;
+  atomic_init(&j.next, 0u);
+  atomic_init(&j.bins, 0ull);
+  atomic_init(&j.bad, 0ull);
+  atomic_init(&j.enc_ns, 0ull);
+  atomic_init(&j.dec_ns, 0ull);
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  const uint64_t t0 = now_ns();
+  for (int t = 1; t < n_threads; t++) pthread_create(&th[t], NULL, mt_worker, &j);
+  mt_worker(&j);
+  for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
+  const uint64_t wall = now_ns() - t0;
+  out[0] = atomic_load(&j.bins);
+  out[1] = atomic_load(&j.bad);
+  out[2] = atomic_load(&j.enc_ns);
+  out[3] = atomic_load(&j.dec_ns);
+  return wall;
+}
+
 /* ---------------------------------------------------------------- start-code emulation count
  * OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181: greedy scan for
  * 00 00 {00,01,02,03}; search_n(found, end - 1, 2, 0) keeps the zero pair inside [0, n-1); after a hit the

@@ -35,7 +35,9 @@
 #include <list>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <set>
 #include <sstream>
@@ -302,6 +304,89 @@ int ref_count_emulations(const uint8_t *bytes, long n) {
     strncpy(g_err, ex.what(), sizeof(g_err) - 1);
     return -1;
   }
+}
+
+// CPU baseline of bench.py on all host cores: substreams [first, first + count) of a batch (descriptor layout of
+// include/cabac_hip.h: rec_offset u64, byte_offset u64, n_records u32, byte_capacity u32, qp i32, init_id u32) through
+// BinEncoder_Std and back through BinDecoder_Std, one substream per task on a std::thread pool.  out = {bins coded,
+// failed substreams, sum over threads of encode ns, of decode ns}; returns the wall time in ns.
+struct RefDesc { uint64_t rec_offset, byte_offset; uint32_t n_records, byte_capacity; int32_t qp; uint32_t init_id; };
+uint64_t ref_roundtrip_mt(const void *desc_, uint32_t first, uint32_t count, const uint16_t *records, int n_threads,
+                          uint64_t *out) {
+  const RefDesc *desc = static_cast<const RefDesc *>(desc_);
+  std::atomic<uint32_t> next{0};
+  std::atomic<uint64_t> bins{0}, bad{0}, enc_ns{0}, dec_ns{0};
+  auto worker = [&]() {
+    std::vector<uint8_t> buf, got;
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= count) break;
+      const RefDesc &d = desc[first + k];
+      const uint16_t *rec = records + d.rec_offset;
+      buf.resize(size_t(d.n_records) + 64);
+      got.resize(size_t(d.n_records) + 1);
+      uint32_t nbits = 0, nread = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      const long nb = ref_encode_records(rec, d.n_records, d.qp, int(d.init_id & 3), 3, buf.data(), long(buf.size()), &nbits);
+      const auto t1 = std::chrono::steady_clock::now();
+      int rc = nb < 0 ? -1 : ref_decode_records(rec, d.n_records, d.qp, int(d.init_id & 3), 1, buf.data(), nb, got.data(), &nread);
+      const auto t2 = std::chrono::steady_clock::now();
+      for (uint32_t i = 0; rc == 0 && i < d.n_records; i++)
+        if (got[i] != (rec[i] >> 15)) rc = -1;
+      bins += d.n_records;
+      enc_ns += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+      dec_ns += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count());
+      if (rc) bad += 1;
+    }
+  };
+  if (n_threads < 1) n_threads = 1;
+  const auto w0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  const auto w1 = std::chrono::steady_clock::now();
+  out[0] = bins;
+  out[1] = bad;
+  out[2] = enc_ns;
+  out[3] = dec_ns;
+  return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(w1 - w0).count());
+}
+
+// InputBitstream (bit_stream.cpp:183-430) driven by the script format of tests/csrc/host_shim_driver.cpp's
+// shim_input_bitstream_script, so that the host mirror can be compared with it step by step
+long ref_input_bitstream_script(const uint8_t *bytes, long n_bytes, const uint32_t *script, long n_steps, uint32_t *out,
+                                uint8_t *sub, long sub_cap) {
+  InputBitstream bs;
+  bs.getFifo().assign(bytes, bytes + n_bytes);
+  long n_sub = 0;
+  for (long i = 0; i < n_steps; i++) {
+    const uint32_t op = script[2 * i], arg = script[2 * i + 1];
+    try {
+      switch (op) {
+      case 0: out[i] = bs.read(arg); break;
+      case 1: out[i] = bs.readByte(); break;
+      case 2: {
+        std::unique_ptr<InputBitstream> r(bs.extractSubstream(arg));
+        out[i] = uint32_t(r->getFifo().size());
+        if (n_sub + (long)r->getFifo().size() > sub_cap) return -3;
+        if (!r->getFifo().empty()) memcpy(sub + n_sub, r->getFifo().data(), r->getFifo().size());
+        n_sub += (long)r->getFifo().size();
+        break;
+      }
+      case 3: out[i] = bs.readOutTrailingBits(); break;
+      case 4: out[i] = bs.getNumBitsLeft(); break;
+      case 5: out[i] = bs.getNumBitsUntilByteAligned(); break;
+      case 6: out[i] = bs.readByteAlignment(); break;
+      default: return -2;
+      }
+    } catch (std::exception &ex) {
+      strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+      out[i] = 0xFFFFFFFFu;
+      return n_sub;
+    }
+  }
+  return n_sub;
 }
 
 // ---- BitEstimator_Std (arith_codec.cpp:603-711): fractional-bit cost of a bin string -----------------

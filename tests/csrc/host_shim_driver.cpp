@@ -127,6 +127,46 @@ int shim_decode_replay(const uint16_t *rec, long n, int qp, int init_id, const u
   }
 }
 
+// GPU: values coded with encodeRemAbsEP (each between two context bins) come back through BinDecoderHip::decodeRemAbsEP.
+// vals[i] = {value, rice, maxLog2TrDynamicRange}; returns 0 and got[i] = the decoded values.
+int shim_rem_abs_round_trip(const uint32_t *vals, long n, int qp, int init_id, uint32_t *got) {
+  try {
+    HipBatch batch(0);
+    BinEncoderHip enc(batch, BinEncoderHip::Immediate);
+    OutputBitstream bs;
+    enc.init(&bs);
+    enc.reset(qp, init_id);
+    enc.start();
+    for (long i = 0; i < n; i++) {
+      enc.encodeBin(unsigned(i & 1), 90 + unsigned(i % 60));
+      enc.encodeRemAbsEP(vals[3 * i], vals[3 * i + 1], 5, int(vals[3 * i + 2]));
+    }
+    enc.encodeBinTrm(1);
+    enc.finish();
+    bs.writeByteAlignment();
+    BinDecoderHip dec(batch);
+    InputBitstream ib;
+    ib.getFifo() = bs.getFIFO();
+    dec.init(&ib);
+    dec.reset(qp, init_id);
+    for (long i = 0; i < n; i++) {
+      dec.planBin(90 + unsigned(i % 60));
+      dec.planRemAbsEP(vals[3 * i], vals[3 * i + 1], 5, int(vals[3 * i + 2]));
+    }
+    dec.planBinTrm();
+    dec.run(true);
+    for (long i = 0; i < n; i++) {
+      if (dec.decodeBin(90 + unsigned(i % 60)) != unsigned(i & 1)) throw Exception("context bin differs");
+      got[i] = dec.decodeRemAbsEP(vals[3 * i + 1], 5, int(vals[3 * i + 2]));
+    }
+    if (dec.decodeBinTrm() != 1) throw Exception("terminate bin differs");
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 // CPU only: OutputBitstream mirror behaviour: sequence of (bits, nbits) writes then optional alignment
 long shim_bitstream_writes(const uint32_t *vals, const uint32_t *nbits, long n, int align, uint8_t *out, long cap,
                            uint32_t *total_bits) {
@@ -147,6 +187,44 @@ long shim_bitstream_writes(const uint32_t *vals, const uint32_t *nbits, long n, 
     return -1;
   }
 }
+// CPU only: InputBitstream mirror.  A script of {op, arg}: 0 read(arg bits) | 1 readByte | 2 extractSubstream(arg bits)
+// (the substream's bytes follow in `sub`, its length in out) | 3 readOutTrailingBits | 4 getNumBitsLeft |
+// 5 getNumBitsUntilByteAligned | 6 readByteAlignment.  out[i] receives the value of step i; a step that throws stores
+// 0xFFFFFFFF and ends the script (the reference's CHECKs).  Returns the number of bytes written to `sub`.
+long shim_input_bitstream_script(const uint8_t *bytes, long n_bytes, const uint32_t *script, long n_steps, uint32_t *out,
+                                 uint8_t *sub, long sub_cap) {
+  InputBitstream bs;
+  bs.getFifo().assign(bytes, bytes + n_bytes);
+  long n_sub = 0;
+  for (long i = 0; i < n_steps; i++) {
+    const uint32_t op = script[2 * i], arg = script[2 * i + 1];
+    try {
+      switch (op) {
+      case 0: out[i] = bs.read(arg); break;
+      case 1: out[i] = bs.readByte(); break;
+      case 2: {
+        std::unique_ptr<InputBitstream> r(bs.extractSubstream(arg));
+        out[i] = uint32_t(r->getFifo().size());
+        if (n_sub + (long)r->getFifo().size() > sub_cap) return -3;
+        if (!r->getFifo().empty()) memcpy(sub + n_sub, r->getFifo().data(), r->getFifo().size());
+        n_sub += (long)r->getFifo().size();
+        break;
+      }
+      case 3: out[i] = bs.readOutTrailingBits(); break;
+      case 4: out[i] = bs.getNumBitsLeft(); break;
+      case 5: out[i] = bs.getNumBitsUntilByteAligned(); break;
+      case 6: out[i] = bs.readByteAlignment(); break;
+      default: return -2;
+      }
+    } catch (std::exception &e) {
+      strncpy(g_err, e.what(), sizeof g_err - 1);
+      out[i] = 0xFFFFFFFFu;
+      return n_sub;
+    }
+  }
+  return n_sub;
+}
+
 // BitEstimatorHip driven like the reference drives BitEstimator_Std in RDO: the op stream is applied in
 // `n_seg` segments; before segment i (i > 0) resetBits() (seg_kind 0), start() (1) or restart() (2) is
 // called and the cost read with getEstFracBits() — costs[i] = the value read at the end of segment i.

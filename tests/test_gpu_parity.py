@@ -15,14 +15,18 @@ from entropy_coding_amd.workload import CONFIGS, build_batch
 pytestmark = pytest.mark.gpu
 
 
-# kernel variants: 0 = auto, 1 = v1 wave-serial, 2 | L << 8 = v2 lane-per-substream with L lanes per wave
-VARIANTS = {"auto": 0, "v1": 1, "v2_L4": 2 | (4 << 8), "v3": 3, "v4": 4, "v5": 5}
+# kernel variants: 0 = auto, 3 = v3 phased wave (auto below 2 048 substreams), 4 = v4 quad, 5 = v5 three-wave
+# encoder.  The superseded v1 (wave-serial) and v2 (lane-per-substream, 2 | L << 8) are never dispatched to by `auto`;
+# they stay selectable and get one parity pass of their own (test_legacy_variants_still_bit_exact), not the whole matrix.
+VARIANTS = {"auto": 0, "v3": 3, "v4": 4, "v5": 5}
+LEGACY_VARIANTS = {"v1": 1, "v2_L4": 2 | (4 << 8)}
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
 def hip(request):
     c = capi.CabacHip(0)   # raises without a GPU: there is no fallback
     c.set_variant(VARIANTS[request.param], VARIANTS[request.param])
+    c.variant_name = request.param
     yield c
     c.close()
 
@@ -231,12 +235,12 @@ def test_synthetic_config_md5_on_gpu(hip, name):
     assert np.array_equal(bins, (records >> 15).astype(np.uint8)) and not rd["flags"].any()
 
 
-def test_full_size_c4_round_trip_device_api(hip):
-    """BASELINE config C4 at full size (4096 substreams x 16384 bins) through the device-pointer API:
-    encode -> decode round trip on all 67 M bins, plus oracle byte parity on a sample of substreams."""
+def _full_size_round_trip(hip, name, sample_stride):
+    """One BASELINE config at full size through the device-pointer API: encode -> decode round trip on every bin, flags
+    clear, plus oracle byte parity on every sample_stride-th substream."""
     import torch
     orc = H.load_oracle()
-    cfg = CONFIGS["C4"]
+    cfg = CONFIGS[name]
     desc, records, total = build_batch(cfg)
     n = len(desc)
     t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
@@ -255,13 +259,62 @@ def test_full_size_c4_round_trip_device_api(hip):
     hip.synchronize()
     res2 = t_res2.cpu().numpy().view(capi.RESULT_DTYPE)
     assert not res2["flags"].any()
+    # (flags clear includes the finish() check: the decoder stands on the stop bit of the last byte)
     want = (t_rec.view(torch.int16) < 0).to(torch.uint8)      # bit 15 of each record
-    assert bool(torch.equal(t_bins, want))
-    out = t_bytes.cpu().numpy()
-    for s in range(0, n, 97):
+    live = torch.zeros(len(records), dtype=torch.bool, device="cuda")   # the stagger gaps between slots are never written
+    for s in range(n):
         o, nr = int(desc["rec_offset"][s]), int(desc["n_records"][s])
-        b, nbits = orc.encode_records(records[o:o + nr], 32, 2, 3)
-        assert nbits == int(res["n_bits"][s]) and np.array_equal(_stream_bytes(out, desc, res, s), b)
+        live[o:o + nr] = True
+    assert bool(torch.equal(t_bins[live], want[live]))
+    del live, want, t_bins
+    out = t_bytes.cpu().numpy()
+    order = build_batch.last_order
+    for s in range(0, n, sample_stride):
+        o, nr = int(desc["rec_offset"][s]), int(desc["n_records"][s])
+        b, nbits = orc.encode_records(records[o:o + nr], int(desc["qp"][s]), 2, 3)
+        assert nbits == int(res["n_bits"][s]) and np.array_equal(_stream_bytes(out, desc, res, s), b), (name, s, int(order[s]))
+
+
+def test_full_size_c4_round_trip_device_api(hip):
+    """BASELINE config C4 at full size (4096 substreams x 16384 bins): 67 M bins, every kernel variant."""
+    _full_size_round_trip(hip, "C4", 97)
+
+
+def test_full_size_c3_round_trip_device_api(hip):
+    """BASELINE config C3 at full size (256 substreams x 524288 bins, QP 0, 45 % bypass): 134 M bins in long substreams —
+    the decode input ring wraps thousands of times, byte positions reach the MB range, and with 256 substreams the
+    dispatcher takes the small-batch kernels (v3 encode, single-wave v4 decode)."""
+    if hip.variant_name != "auto":
+        pytest.skip("full-size C3 runs on the dispatched variants only")
+    _full_size_round_trip(hip, "C3", 37)
+
+
+def test_full_size_c5_round_trip_device_api(hip):
+    """BASELINE config C5 at full size (8192 substreams, half 2048 bins at QP 51, half 262144 at QP 0, LPT ordered): 1.08 G
+    bins — mixed lengths inside the batch, rows that idle for most of their wave's life at the boundary."""
+    if hip.variant_name != "auto":
+        pytest.skip("full-size C5 runs on the dispatched variants only")
+    _full_size_round_trip(hip, "C5", 409)
+
+
+def test_legacy_variants_still_bit_exact():
+    """v1 / v2 (never dispatched to, kept selectable): one ragged random batch each against the oracle."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 17, 5000] + [int(x) for x in rng.integers(0, 3000, size=60)]
+    recs = [H.random_records(rng, max(n - 1, 0), end_trm=(n > 0)) for n in lens]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), rng.integers(0, 3, size=len(lens)),
+                              H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    for name, v in LEGACY_VARIANTS.items():
+        c = capi.CabacHip(0)
+        c.set_variant(v, v)
+        out, res = _compare_encode(c, orc, desc, records, total)
+        dd = desc.copy(); dd["byte_capacity"] = (res["n_bits"] + 7) // 8
+        bins, rd = c.decode_batch(dd, records, out)
+        assert np.array_equal(bins, (records >> 15).astype(np.uint8)) and not rd["flags"].any(), name
+        c.close()
 
 
 _UNITS_SCRIPT = r'''

@@ -41,6 +41,9 @@ def drv():
     L.shim_estimate_segments.argtypes = [u32p, lp, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, ctypes.c_int, u16p,
                                          ctypes.c_long]
     L.shim_estimate_many.argtypes = [u16p, lp, ctypes.c_int, ip, ip, u64p]
+    L.shim_rem_abs_round_trip.argtypes = [u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, u32p]
+    L.shim_input_bitstream_script.restype = ctypes.c_long
+    L.shim_input_bitstream_script.argtypes = [u8p, ctypes.c_long, u32p, ctypes.c_long, u32p, u8p, ctypes.c_long]
     L.shim_bitstream_writes.restype = ctypes.c_long
     L.shim_bitstream_writes.argtypes = [u32p, u32p, ctypes.c_long, ctypes.c_int, u8p, ctypes.c_long, u32p]
     return L
@@ -107,6 +110,103 @@ def test_output_bitstream_mirror(drv):
         assert got == len(want) and out[:got].tobytes() == want
 
 
+def _input_script_model(data, script):
+    """Independent bit-string model of InputBitstream (bit_stream.cpp:183-430)."""
+    bits = "".join(format(b, "08b") for b in data)
+    pos, out, sub = 0, [], bytearray()
+
+    def take(n):
+        nonlocal pos
+        need_bytes = -(-(pos + n) // 8)
+        if need_bytes > len(data):
+            raise IndexError
+        v = int(bits[pos:pos + n], 2) if n else 0
+        pos += n
+        return v
+
+    for op, arg in script:
+        try:
+            if op == 0:
+                out.append(take(arg))
+            elif op == 1:            # readByte only ever runs byte aligned in the reference's callers
+                assert pos % 8 == 0
+                out.append(take(8))
+            elif op == 2:
+                nbytes, tail = arg // 8, arg % 8
+                chunk = bytearray()
+                if pos % 8 == 0:     # aligned: copies what is there, pads with zeros
+                    avail = min(nbytes, len(data) - pos // 8)
+                    chunk += bytes(data[pos // 8: pos // 8 + avail]) + bytes(nbytes - avail)
+                    pos += 8 * avail
+                else:
+                    for _ in range(nbytes):
+                        chunk.append(take(8))
+                if tail:
+                    chunk.append(take(tail) << (8 - tail))
+                out.append(len(chunk))
+                sub += chunk
+            elif op == 3:
+                n = 0
+                while 8 * len(data) - pos > 0 and pos % 8:
+                    take(1)
+                    n += 1
+                out.append(n)
+            elif op == 4:
+                out.append(8 * len(data) - pos)
+            elif op == 5:
+                out.append(-pos % 8)
+            elif op == 6:
+                if take(1) != 1:
+                    raise IndexError
+                n = -pos % 8
+                if n and take(n) != 0:
+                    raise IndexError
+                out.append(n + 1)
+        except IndexError:
+            out.append(0xFFFFFFFF)
+            break
+    return out, bytes(sub)
+
+
+def _run_input_script(fn, data, script):
+    sc = np.ascontiguousarray(script, np.uint32).reshape(-1, 2)
+    out = np.zeros(len(sc), np.uint32)
+    sub = np.zeros(len(data) + 8 * len(sc) + 8, np.uint8)
+    n = fn(H._ptr(data, u8p), len(data), H._ptr(sc, u32p), len(sc), H._ptr(out, u32p), H._ptr(sub, u8p), len(sub))
+    assert n >= 0
+    return out, sub[:n].tobytes()
+
+
+def test_input_bitstream_mirror(drv):
+    """read / readOutTrailingBits / extractSubstream at any bit position / readByteAlignment of the InputBitstream
+    mirror against a bit-string model and, where it is built, against the reference's own class."""
+    rng = np.random.default_rng(22)
+    ref = None
+    if H.ref_available():
+        ref = H.load_ref().lib.ref_input_bitstream_script
+        ref.restype = ctypes.c_long
+        ref.argtypes = drv.shim_input_bitstream_script.argtypes
+    for trial in range(200):
+        data = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)
+        if trial % 3 == 0:
+            data[rng.integers(0, len(data))] = 0x80      # a byte that passes readByteAlignment
+        script, aligned = [], True
+        for _ in range(int(rng.integers(1, 12))):
+            op = int(rng.choice([0, 0, 0, 2, 2, 3, 4, 5, 6] + ([1] if aligned else [])))
+            arg = int(rng.integers(0, 33)) if op == 0 else int(rng.integers(0, 8 * len(data) + 9)) if op == 2 else 0
+            script.append((op, arg))
+            aligned = op in (3, 6) or (aligned and op in (1, 4, 5)) or (aligned and op in (0, 2) and arg % 8 == 0)
+        want, want_sub = _input_script_model(data, script)
+        got, got_sub = _run_input_script(drv.shim_input_bitstream_script, data, script)
+        n = len(want)
+        assert list(got[:n]) == want, (trial, script, want, list(got[:n]))
+        if want[-1] != 0xFFFFFFFF:
+            assert got_sub == want_sub
+        if ref is not None:
+            rgot, rsub = _run_input_script(ref, data, script)
+            assert list(rgot[:n]) == want and (want[-1] == 0xFFFFFFFF or rsub == want_sub), (trial, script)
+
+
 # ------------------------------------------------------------------ GPU
 def _encode_streams(drv, op_list, qps, ids, mode, flags):
     n = len(op_list)
@@ -168,6 +268,26 @@ def test_shim_decode_replay(drv):
     rc = drv.shim_decode_replay(H._ptr(rec, u16p), len(rec), 27, 2, H._ptr(buf, u8p), len(data) // 2, 1,
                                 H._ptr(bins, u8p), ctypes.byref(idx))
     assert rc == -1 and b"FIFO exceeded" in drv.shim_last_error()
+
+
+@pytest.mark.gpu
+def test_shim_decode_rem_abs(drv):
+    """BinDecoderHip::decodeRemAbsEP (arith_codec.cpp:153-179) returns what encodeRemAbsEP coded: short and escape
+    codes, every Rice parameter, the longest prefix, extended dynamic range."""
+    rng = np.random.default_rng(92)
+    vals = []
+    for i in range(400):
+        rice = int(rng.integers(0, 5))
+        max_log2 = int(rng.choice([15, 15, 15, 17, 20]))
+        kind = i % 4
+        v = int(rng.integers(0, 5 << rice)) if kind == 0 else int(rng.integers(0, 300)) if kind == 1 else \
+            int(rng.integers(0, 1 << 15)) if kind == 2 else (1 << max_log2) - 1 - int(rng.integers(0, 3))
+        vals.append((v, rice, max_log2))
+    a = np.array(vals, np.uint32)
+    got = np.zeros(len(a), np.uint32)
+    rc = drv.shim_rem_abs_round_trip(H._ptr(a, u32p), len(a), 30, 2, H._ptr(got, u32p))
+    assert rc == 0, drv.shim_last_error()
+    assert np.array_equal(got, a[:, 0])
 
 
 # ---- bit estimator shim (BitEstimatorHip / HipBatch::estimate) ----------------------------------------
