@@ -72,6 +72,27 @@ def _cpu_model():
     return "unknown"
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where one is set
+    (a GPU box gives each lease a share of the host, not all of its cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    if os.environ.get("CABAC_BENCH_CPU_THREADS"):
+        n = int(os.environ["CABAC_BENCH_CPU_THREADS"])
+    return n
+
+
 def cpu_baseline(cfg, desc, records, budget_s):
     """Reference CPU path timed on this host on a bounded sample of the same workload: one substream per task on a
     native thread pool (std::thread / pthreads inside the checker library), first with 1 thread, then with every core
@@ -88,7 +109,7 @@ def cpu_baseline(cfg, desc, records, budget_s):
     run.restype = ctypes.c_uint64
     run.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     n_sub = len(desc)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _usable_cores()
     desc = np.ascontiguousarray(desc)
 
     def leg(first, count, threads):
@@ -103,9 +124,17 @@ def cpu_baseline(cfg, desc, records, budget_s):
     per_sub = wall_p / probe
     n1 = int(max(1, min(n_sub, (budget_s / 2) / per_sub)))
     bins1, wall1, enc1, dec1 = leg(0, n1, 1)
-    nall = int(max(cores, min(n_sub, (budget_s / 2) / per_sub * cores)))
-    nall = min(nall, n_sub)
-    bins_a, wall_a, enc_a, dec_a = leg(0, nall, cores)
+    # all cores: the lease's share of the host is not always visible (no cgroup quota file), so 16 threads — the share
+    # of a one-GPU lease — are tried beside the full affinity mask and the faster is reported with its thread count
+    best = None
+    cands = sorted({min(cores, 16), cores})
+    for th in cands:
+        leg(0, min(n_sub, 2 * th), th)  # wake the cores up (the first threaded pass on an idle host runs far below its rate)
+        nall = min(n_sub, int(max(th, (budget_s / 2 / len(cands)) / per_sub * min(th, 16))))
+        bins_t, wall_t, _, _ = leg(0, nall, th)
+        if best is None or bins_t / wall_t > best[0] / best[1]:
+            best = (bins_t, wall_t, th, nall)
+    bins_a, wall_a, cores, nall = best
     return {
         "value": round(2 * bins_a / wall_a / 1e6, 2),
         "unit": "Mbins/s",

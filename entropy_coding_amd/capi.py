@@ -32,6 +32,8 @@ EXPORTS = [
     "cabac_hip_last_kernel_ms", "cabac_synth_records", "cabac_hip_profile_enable", "cabac_hip_profile_read",
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
+    "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
+    "cabac_hip_host_is_pinned",
 ]
 
 _lib = None
@@ -84,6 +86,11 @@ def load_library():
     L.cabac_hip_estimate_from_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.cabac_hip_profile_read.argtypes = [vp, vp, vp, ctypes.c_uint32]
+    L.cabac_hip_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.cabac_hip_host_free.argtypes = [vp]
+    L.cabac_hip_host_register.argtypes = [vp, ctypes.c_size_t]
+    L.cabac_hip_host_unregister.argtypes = [vp]
+    L.cabac_hip_host_is_pinned.argtypes = [vp, ctypes.c_size_t]
     L.cabac_synth_records.restype = None
     L.cabac_synth_records.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, vp]
     _lib = L
@@ -101,6 +108,40 @@ def synth_records(seed, substream_index, n_bins, ctx_permille):
     out = np.empty(n_bins, np.uint16)
     L.cabac_synth_records(seed, substream_index, n_bins, ctx_permille, out.ctypes.data)
     return out
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory from cabac_hip_host_alloc (freed with close() / garbage collection):
+    buffers the host-pointer entry points DMA without a staging copy."""
+
+    def __init__(self, shape, dtype):
+        L = load_library()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = vp()
+        rc = L.cabac_hip_host_alloc(max(n, 1), ctypes.byref(p))
+        if rc != 0:
+            raise CabacHipError(rc, "cabac_hip_host_alloc(%d)" % n)
+        self._p = p
+        buf = (ctypes.c_uint8 * max(n, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            load_library().cabac_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_is_pinned(a):
+    a = np.asarray(a)
+    return bool(load_library().cabac_hip_host_is_pinned(vp(a.ctypes.data), a.nbytes))
 
 
 def encode_bound(n_ctx, n_ep, n_trm):
@@ -161,21 +202,24 @@ class CabacHip:
         return list(zip(kind[:n].tolist(), ms[:n].tolist()))
 
     # ---- host-pointer entry points (numpy) --------------------------------------------------
-    def encode_batch(self, desc, records, bytes_total, check=True):
+    def encode_batch(self, desc, records, bytes_total, check=True, out=None):
+        """`out` (optional): the caller's byte buffer (e.g. PinnedArray(...).array), else a fresh zeroed array."""
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         records = np.ascontiguousarray(records, np.uint16)
-        out = np.zeros(max(int(bytes_total), 1), np.uint8)
+        if out is None:
+            out = np.zeros(max(int(bytes_total), 1), np.uint8)
         res = np.zeros(len(desc), RESULT_DTYPE)
         rc = self.L.cabac_hip_encode_batch(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
                                            out.ctypes.data, int(bytes_total), res.ctypes.data)
         self._check(rc, allow_substream=not check)
         return out, res
 
-    def decode_batch(self, desc, records, data, check=True):
+    def decode_batch(self, desc, records, data, check=True, bins=None):
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         records = np.ascontiguousarray(records, np.uint16)
         data = np.ascontiguousarray(data, np.uint8)
-        bins = np.zeros(max(len(records), 1), np.uint8)
+        if bins is None:
+            bins = np.zeros(max(len(records), 1), np.uint8)
         res = np.zeros(len(desc), RESULT_DTYPE)
         rc = self.L.cabac_hip_decode_batch(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
                                            data.ctypes.data, len(data), bins.ctypes.data, res.ctypes.data)

@@ -1,12 +1,19 @@
 // C ABI of libcabac_hip.so (declared in include/cabac_hip.h).  Host-side plumbing only: argument
-// checks, stream/event handling, pinned staging for the host-pointer entry points.  There is no
+// checks, stream/event handling, and the host-pointer entry points' path over PCIe: pinned host memory
+// (cabac_hip_host_alloc / _register) is DMA'd directly, pageable memory goes through a ring of pinned bounce
+// blocks, a batch is cut into chunks whose H2D copy, kernel and D2H copy run on separate streams, and coded
+// substreams leave the device compacted (cabac_assemble.hip) in one copy per chunk.  There is no
 // CPU codec in this library — without a GPU cabac_hip_init fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "cabac_hip.h"
@@ -24,9 +31,27 @@ struct cabac_hip_ctx {
   std::vector<hipEvent_t> prof_ev;  // 2 per slot
   std::vector<int32_t> prof_kind;
   uint32_t prof_n = 0;
-  // staging for the host-pointer entry points (grown on demand)
-  void *d_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [5]: scratch of the residual binariser
-  size_t d_cap[6] = {0, 0, 0, 0, 0, 0};
+  // device staging for the host-pointer entry points (grown on demand)
+  // [5]: scratch of the residual binariser, [6]: compacted payload, [7]: payload offsets
+  void *d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // ---- the PCIe path of the host-pointer entry points -------------------------------------------------
+  static constexpr int kKernelStreams = 4, kMaxChunks = 8, kBounceDepth = 4;
+  static constexpr size_t kBounceBlock = size_t(4) << 20;
+  hipStream_t s_in = nullptr, s_out = nullptr, s_k[kKernelStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_out[kMaxChunks] = {};
+  struct Bounce {  // ring of pinned blocks between pageable caller memory and the DMA engines
+    void *blk[kBounceDepth] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kBounceDepth] = {nullptr, nullptr, nullptr, nullptr};
+    bool busy[kBounceDepth] = {false, false, false, false};
+    void *dst[kBounceDepth] = {nullptr, nullptr, nullptr, nullptr};  // D2H: where the block goes once it has arrived
+    size_t len[kBounceDepth] = {0, 0, 0, 0};
+    int next = 0;
+  } bounce_in, bounce_out;
+  void *h_pin[2] = {nullptr, nullptr};  // pinned: [0] results + payload offsets coming back, [1] compacted payload
+  size_t h_cap[2] = {0, 0};
+  bool pipe_ready = false;
+  int chunks_override = 0;  // CABAC_HIP_CHUNKS (experiments); 0 = by batch size
 };
 
 namespace {
@@ -107,6 +132,203 @@ int check_desc_host(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc
   return CABAC_HIP_OK;
 }
 
+
+// ---- pinned host memory handed out by cabac_hip_host_alloc / pinned in place by cabac_hip_host_register ----
+std::mutex g_host_mu;
+std::unordered_map<const void *, size_t> g_host_owned, g_host_registered;
+
+bool host_is_pinned(const void *p, size_t bytes) {
+  if (!p) return false;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (const auto *m : {&g_host_owned, &g_host_registered})
+      for (const auto &kv : *m) {
+        const uint8_t *b = static_cast<const uint8_t *>(kv.first), *q = static_cast<const uint8_t *>(p);
+        if (q >= b && q + bytes <= b + kv.second) return true;
+      }
+  }
+  hipPointerAttribute_t a;  // pinned by somebody else (e.g. torch's pin_memory)
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+void pipe_destroy(cabac_hip_ctx *c) {
+  for (hipStream_t st : {c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
+    if (st) (void)hipStreamDestroy(st);
+  for (int i = 0; i < cabac_hip_ctx::kMaxChunks; i++)
+    for (hipEvent_t e : {c->ev_in[i], c->ev_k[i], c->ev_out[i]})
+      if (e) (void)hipEventDestroy(e);
+  for (cabac_hip_ctx::Bounce *b : {&c->bounce_in, &c->bounce_out})
+    for (int i = 0; i < cabac_hip_ctx::kBounceDepth; i++) {
+      if (b->blk[i]) (void)hipHostFree(b->blk[i]);
+      if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+    }
+  for (void *p : c->h_pin)
+    if (p) (void)hipHostFree(p);
+  c->pipe_ready = false;
+}
+
+int pipe_init(cabac_hip_ctx *c) {
+  if (c->pipe_ready) return CABAC_HIP_OK;
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+  for (hipStream_t &st : c->s_k) HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  for (int i = 0; i < cabac_hip_ctx::kMaxChunks; i++) {
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+  }
+  for (cabac_hip_ctx::Bounce *b : {&c->bounce_in, &c->bounce_out})
+    for (int i = 0; i < cabac_hip_ctx::kBounceDepth; i++) {
+      HIP_TRY(c, hipHostMalloc(&b->blk[i], cabac_hip_ctx::kBounceBlock, hipHostMallocDefault));
+      HIP_TRY(c, hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming));
+    }
+  if (const char *e = getenv("CABAC_HIP_CHUNKS")) c->chunks_override = atoi(e);
+  c->pipe_ready = true;
+  return CABAC_HIP_OK;
+}
+
+int ensure_pinned(cabac_hip_ctx *c, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (c->h_cap[slot] >= bytes) return CABAC_HIP_OK;
+  if (c->h_pin[slot]) {
+    HIP_TRY(c, hipHostFree(c->h_pin[slot]));
+    c->h_pin[slot] = nullptr;
+    c->h_cap[slot] = 0;
+  }
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc(&c->h_pin[slot], want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    c->last_error = "hipHostMalloc failed";
+    return CABAC_HIP_ERR_NOMEM;
+  }
+  c->h_cap[slot] = want;
+  return CABAC_HIP_OK;
+}
+
+// grow pinned slot `slot` to `bytes`, keeping its first `keep` bytes (copies into them may still be in flight on s_out)
+int ensure_pinned_keep(cabac_hip_ctx *c, int slot, size_t bytes, size_t keep) {
+  if (c->h_cap[slot] >= bytes && c->h_pin[slot]) return CABAC_HIP_OK;
+  void *old = c->h_pin[slot];
+  if (old && keep) HIP_TRY(c, hipStreamSynchronize(c->s_out));
+  c->h_pin[slot] = nullptr;
+  c->h_cap[slot] = 0;
+  int rc = ensure_pinned(c, slot, bytes + bytes);  // chunks are about equal: leave room for the ones to come
+  if (rc == CABAC_HIP_OK && old && keep) std::memcpy(c->h_pin[slot], old, keep);
+  if (old) (void)hipHostFree(old);
+  return rc;
+}
+
+// host -> device on `st`: pinned memory is DMA'd where it lies; pageable memory is copied block by block into the
+// pinned ring, each block's DMA overlapping the host copy of the next one
+int h2d(cabac_hip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return CABAC_HIP_OK;
+  if (host_is_pinned(src, bytes)) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return CABAC_HIP_OK;
+  }
+  cabac_hip_ctx::Bounce &b = c->bounce_in;
+  for (size_t off = 0; off < bytes; off += cabac_hip_ctx::kBounceBlock) {
+    const size_t n = std::min(cabac_hip_ctx::kBounceBlock, bytes - off);
+    const int i = b.next;
+    b.next = (i + 1) % cabac_hip_ctx::kBounceDepth;
+    if (b.busy[i]) HIP_TRY(c, hipEventSynchronize(b.ev[i]));
+    std::memcpy(b.blk[i], static_cast<const uint8_t *>(src) + off, n);
+    HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(dst) + off, b.blk[i], n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipEventRecord(b.ev[i], st));
+    b.busy[i] = true;
+  }
+  return CABAC_HIP_OK;
+}
+
+// one block of the outgoing ring has arrived: hand it to the caller's memory
+int d2h_retire(cabac_hip_ctx *c, int i) {
+  cabac_hip_ctx::Bounce &b = c->bounce_out;
+  if (!b.busy[i]) return CABAC_HIP_OK;
+  HIP_TRY(c, hipEventSynchronize(b.ev[i]));
+  std::memcpy(b.dst[i], b.blk[i], b.len[i]);
+  b.busy[i] = false;
+  return CABAC_HIP_OK;
+}
+
+// device -> host on `st`; for pageable memory the data is complete only after d2h_drain
+int d2h(cabac_hip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return CABAC_HIP_OK;
+  if (host_is_pinned(dst, bytes)) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    return CABAC_HIP_OK;
+  }
+  cabac_hip_ctx::Bounce &b = c->bounce_out;
+  for (size_t off = 0; off < bytes; off += cabac_hip_ctx::kBounceBlock) {
+    const size_t n = std::min(cabac_hip_ctx::kBounceBlock, bytes - off);
+    const int i = b.next;
+    b.next = (i + 1) % cabac_hip_ctx::kBounceDepth;
+    if (int rc = d2h_retire(c, i)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(b.blk[i], static_cast<const uint8_t *>(src) + off, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(b.ev[i], st));
+    b.busy[i] = true;
+    b.dst[i] = static_cast<uint8_t *>(dst) + off;
+    b.len[i] = n;
+  }
+  return CABAC_HIP_OK;
+}
+
+int d2h_drain(cabac_hip_ctx *c) {
+  for (int k = 0; k < cabac_hip_ctx::kBounceDepth; k++) {
+    const int i = (c->bounce_out.next + k) % cabac_hip_ctx::kBounceDepth;  // oldest first
+    if (int rc = d2h_retire(c, i)) return rc;
+  }
+  return CABAC_HIP_OK;
+}
+
+// A batch cut at substream boundaries into chunks of about equal record counts.  Chunks need the substreams' record
+// and byte slots in ascending, non-overlapping order (what every packer produces); otherwise the batch is one chunk.
+struct Chunk {
+  uint32_t s0, s1;
+  uint64_t rec_lo, rec_hi, byte_lo, byte_hi;
+};
+
+std::vector<Chunk> plan_chunks(const cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc) {
+  uint64_t rec_end = 0, byte_end = 0, total = 0;
+  bool ordered = true;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    ordered = ordered && desc[s].rec_offset >= rec_end && desc[s].byte_offset >= byte_end;
+    rec_end = std::max<uint64_t>(rec_end, desc[s].rec_offset + desc[s].n_records);
+    byte_end = std::max<uint64_t>(byte_end, desc[s].byte_offset + desc[s].byte_capacity);
+    total += desc[s].n_records;
+  }
+  // A chunk must still fill a fair part of the chip on its own (the kernels' time does not shrink below ~1 024
+  // substreams) and be worth its launches: by default one chunk per 1 024 substreams and per 8 M records, at most 4.
+  int want = c->chunks_override > 0 ? c->chunks_override : (int)std::min<uint64_t>(std::min<uint64_t>(n_sub / 1024u, total >> 23), 4u);
+  want = std::max(1, std::min(want, (int)cabac_hip_ctx::kMaxChunks));
+  if (!ordered || (uint32_t)want > n_sub) want = 1;
+  std::vector<Chunk> out;
+  uint32_t s = 0;
+  uint64_t done = 0;
+  for (int k = 0; k < want; k++) {
+    Chunk ch;
+    ch.s0 = s;
+    const uint64_t goal = total * uint64_t(k + 1) / uint64_t(want);
+    while (s < n_sub && (done < goal || k == want - 1)) done += desc[s++].n_records;
+    if (k == want - 1) s = n_sub;
+    ch.s1 = s;
+    if (ch.s1 == ch.s0) continue;
+    ch.rec_lo = ch.byte_lo = ~0ull;
+    ch.rec_hi = ch.byte_hi = 0;
+    for (uint32_t q = ch.s0; q < ch.s1; q++) {
+      ch.rec_lo = std::min<uint64_t>(ch.rec_lo, desc[q].rec_offset);
+      ch.rec_hi = std::max<uint64_t>(ch.rec_hi, desc[q].rec_offset + desc[q].n_records);
+      ch.byte_lo = std::min<uint64_t>(ch.byte_lo, desc[q].byte_offset);
+      ch.byte_hi = std::max<uint64_t>(ch.byte_hi, desc[q].byte_offset + desc[q].byte_capacity);
+    }
+    out.push_back(ch);
+  }
+  return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -143,8 +365,9 @@ void cabac_hip_destroy(cabac_hip_ctx *c) {
   if (!c) return;
   DeviceGuard g(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 8; i++)
     if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
+  pipe_destroy(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -344,30 +567,77 @@ int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
   if (rc) return rc;
   DeviceGuard g(c->device);
+  if ((rc = pipe_init(c))) return rc;
+  const std::vector<Chunk> chunks = plan_chunks(c, n_sub, desc);
+  const uint32_t nc = uint32_t(chunks.size());
+  // device: [0] descriptors, [1] records, [2] byte slots, [3] results, [6] compacted payload (chunk k from its byte_lo),
+  // [7] payload offsets (chunk k: n_k + 1 entries from s0 + k).  pinned: [0] results then offsets, [1] payload.
+  const size_t res_bytes = size_t(n_sub) * sizeof(cabac_substream_result);
+  const size_t off_count = size_t(n_sub) + nc;
   if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
   if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
   if ((rc = ensure(c, 2, bytes_total))) return rc;
-  if ((rc = ensure(c, 3, n_sub * sizeof(cabac_substream_result)))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
-  if (n_records_total)
-    HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], records, n_records_total * 2, hipMemcpyHostToDevice, c->stream));
-  rc = cabac_hip_encode_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint16_t *)c->d_buf[1],
-                               (uint8_t *)c->d_buf[2], (cabac_substream_result *)c->d_buf[3]);
-  if (rc) return rc;
-  HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[3], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost,
-                            c->stream));
+  if ((rc = ensure(c, 3, res_bytes))) return rc;
+  if ((rc = ensure(c, 6, bytes_total))) return rc;
+  if ((rc = ensure(c, 7, off_count * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure_pinned(c, 0, res_bytes + off_count * sizeof(uint64_t)))) return rc;
+  auto *d_desc = static_cast<const cabac_substream_desc *>(c->d_buf[0]);
+  auto *d_rec = static_cast<uint16_t *>(c->d_buf[1]);
+  auto *d_slots = static_cast<uint8_t *>(c->d_buf[2]);
+  auto *d_res = static_cast<cabac_substream_result *>(c->d_buf[3]);
+  auto *d_pay = static_cast<uint8_t *>(c->d_buf[6]);
+  auto *d_off = static_cast<uint64_t *>(c->d_buf[7]);
+  auto *h_res = static_cast<cabac_substream_result *>(c->h_pin[0]);
+  auto *h_off = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(c->h_pin[0]) + res_bytes);
+
+  // what came before on the caller's stream is finished first; everything below runs on the library's own streams
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  // copy back only what was produced, substream by substream (payload is ~0.1 B/bin)
-  int status = CABAC_HIP_OK;
-  for (uint32_t s = 0; s < n_sub; s++) {
-    size_t nbytes = (results[s].n_bits + 7) / 8;
-    if (nbytes > desc[s].byte_capacity) nbytes = desc[s].byte_capacity;
-    if (nbytes)
-      HIP_TRY(c, hipMemcpyAsync(bytes + desc[s].byte_offset, (uint8_t *)c->d_buf[2] + desc[s].byte_offset, nbytes,
-                                hipMemcpyDeviceToHost, c->stream));
-    if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+  if ((rc = h2d(c, c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), c->s_in))) return rc;
+  for (uint32_t k = 0; k < nc; k++) {
+    const Chunk &ch = chunks[k];
+    const uint32_t n_k = ch.s1 - ch.s0;
+    if ((rc = h2d(c, d_rec + ch.rec_lo, records + ch.rec_lo, (ch.rec_hi - ch.rec_lo) * 2, c->s_in))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_in[k], c->s_in));
+    hipStream_t ks = c->s_k[k % cabac_hip_ctx::kKernelStreams];
+    HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_in[k], 0));
+    Bracket br = bracket_for(c, 0);
+    HIP_TRY(c, hipEventRecord(br.a, ks));
+    HIP_TRY(c, cabac::launch_encode(ks, c->enc_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_res + ch.s0, n_sub));
+    HIP_TRY(c, hipEventRecord(br.b, ks));
+    c->timed = (br.a == c->ev_start) && nc == 1;
+    // compaction: the coded substreams of the chunk back to back, so that they leave in ONE copy instead of one per
+    // substream (the payload is ~0.1 B/bin; the slots are sized for the worst case)
+    HIP_TRY(c, cabac::launch_assemble(ks, n_k, d_desc + ch.s0, d_res + ch.s0, d_slots, d_pay + ch.byte_lo,
+                                      ch.byte_hi - ch.byte_lo, d_off + ch.s0 + k));
+    HIP_TRY(c, hipMemcpyAsync(h_res + ch.s0, d_res + ch.s0, n_k * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, ks));
+    HIP_TRY(c, hipMemcpyAsync(h_off + ch.s0 + k, d_off + ch.s0 + k, (size_t(n_k) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
+    HIP_TRY(c, hipEventRecord(c->ev_k[k], ks));
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // the sizes of chunk k are known once its kernel is through: its payload follows while later chunks are still coded
+  std::vector<uint64_t> pay_base(nc + 1, 0);
+  for (uint32_t k = 0; k < nc; k++) {
+    const Chunk &ch = chunks[k];
+    HIP_TRY(c, hipEventSynchronize(c->ev_k[k]));
+    const uint64_t n_pay = h_off[ch.s1 + k];
+    pay_base[k + 1] = pay_base[k] + n_pay;
+    if ((rc = ensure_pinned_keep(c, 1, pay_base[k + 1], pay_base[k]))) return rc;
+    if (n_pay)
+      HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(c->h_pin[1]) + pay_base[k], d_pay + ch.byte_lo, n_pay, hipMemcpyDeviceToHost, c->s_out));
+    HIP_TRY(c, hipEventRecord(c->ev_out[k], c->s_out));
+  }
+  int status = CABAC_HIP_OK;
+  for (uint32_t k = 0; k < nc; k++) {
+    const Chunk &ch = chunks[k];
+    HIP_TRY(c, hipEventSynchronize(c->ev_out[k]));
+    const uint8_t *pay = static_cast<const uint8_t *>(c->h_pin[1]) + pay_base[k];
+    const uint64_t *off = h_off + ch.s0 + k;
+    for (uint32_t s = ch.s0; s < ch.s1; s++) {  // into the caller's slots, as the reference's FIFOs hold them
+      const uint64_t o = off[s - ch.s0], n = off[s - ch.s0 + 1] - o;
+      if (n && bytes) std::memcpy(bytes + desc[s].byte_offset, pay + o, n);
+      results[s] = h_res[s];
+      if (h_res[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+    }
+  }
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
 }
@@ -414,30 +684,55 @@ int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
   if (rc) return rc;
   DeviceGuard g(c->device);
+  if ((rc = pipe_init(c))) return rc;
+  const std::vector<Chunk> chunks = plan_chunks(c, n_sub, desc);
+  const uint32_t nc = uint32_t(chunks.size());
+  const size_t res_bytes = size_t(n_sub) * sizeof(cabac_substream_result);
+  // the kernel reads whole aligned dwords: room for the dword that holds the last byte
   if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
   if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
-  if ((rc = ensure(c, 2, bytes_total))) return rc;
-  if ((rc = ensure(c, 3, n_sub * sizeof(cabac_substream_result)))) return rc;
+  if ((rc = ensure(c, 2, bytes_total + 4))) return rc;
+  if ((rc = ensure(c, 3, res_bytes))) return rc;
   if ((rc = ensure(c, 4, n_records_total))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), hipMemcpyHostToDevice, c->stream));
-  if (n_records_total)
-    HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], records, n_records_total * 2, hipMemcpyHostToDevice, c->stream));
-  if (bytes_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[2], bytes, bytes_total, hipMemcpyHostToDevice, c->stream));
-  rc = cabac_hip_decode_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint16_t *)c->d_buf[1],
-                               (const uint8_t *)c->d_buf[2], (uint8_t *)c->d_buf[4],
-                               (cabac_substream_result *)c->d_buf[3]);
-  if (rc) return rc;
-  HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[3], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost,
-                            c->stream));
-  if (n_records_total)
-    HIP_TRY(c, hipMemcpyAsync(bins, c->d_buf[4], n_records_total, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = ensure_pinned(c, 0, res_bytes))) return rc;
+  auto *d_desc = static_cast<const cabac_substream_desc *>(c->d_buf[0]);
+  auto *d_rec = static_cast<uint16_t *>(c->d_buf[1]);
+  auto *d_slots = static_cast<uint8_t *>(c->d_buf[2]);
+  auto *d_res = static_cast<cabac_substream_result *>(c->d_buf[3]);
+  auto *d_bins = static_cast<uint8_t *>(c->d_buf[4]);
+  auto *h_res = static_cast<cabac_substream_result *>(c->h_pin[0]);
+
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (uint32_t s = 0; s < n_sub; s++)
-    if (results[s].flags) {
-      c->last_error = "substream flag set (see results[].flags)";
-      return CABAC_HIP_ERR_SUBSTREAM;
-    }
-  return CABAC_HIP_OK;
+  if ((rc = h2d(c, c->d_buf[0], desc, n_sub * sizeof(cabac_substream_desc), c->s_in))) return rc;
+  for (uint32_t k = 0; k < nc; k++) {
+    const Chunk &ch = chunks[k];
+    const uint32_t n_k = ch.s1 - ch.s0;
+    if ((rc = h2d(c, d_rec + ch.rec_lo, records + ch.rec_lo, (ch.rec_hi - ch.rec_lo) * 2, c->s_in))) return rc;
+    if (bytes && (rc = h2d(c, d_slots + ch.byte_lo, bytes + ch.byte_lo, ch.byte_hi - ch.byte_lo, c->s_in))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_in[k], c->s_in));
+    hipStream_t ks = c->s_k[k % cabac_hip_ctx::kKernelStreams];
+    HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_in[k], 0));
+    Bracket br = bracket_for(c, 1);
+    HIP_TRY(c, hipEventRecord(br.a, ks));
+    HIP_TRY(c, cabac::launch_decode(ks, c->dec_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_bins, d_res + ch.s0, n_sub));
+    HIP_TRY(c, hipEventRecord(br.b, ks));
+    c->timed = (br.a == c->ev_start) && nc == 1;
+    HIP_TRY(c, hipMemcpyAsync(h_res + ch.s0, d_res + ch.s0, n_k * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, ks));
+    HIP_TRY(c, hipEventRecord(c->ev_k[k], ks));
+    // the decoded bins of the chunk leave while the next chunk is decoded
+    HIP_TRY(c, hipStreamWaitEvent(c->s_out, c->ev_k[k], 0));
+    if (bins && (rc = d2h(c, bins + ch.rec_lo, d_bins + ch.rec_lo, ch.rec_hi - ch.rec_lo, c->s_out))) return rc;
+  }
+  if ((rc = d2h_drain(c))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->s_out));
+  for (uint32_t k = 0; k < nc; k++) HIP_TRY(c, hipEventSynchronize(c->ev_k[k]));
+  int status = CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    results[s] = h_res[s];
+    if (h_res[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+  }
+  if (status) c->last_error = "substream flag set (see results[].flags)";
+  return status;
 }
 
 int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t n_sub, const uint64_t *d_se_offset, const uint32_t *d_se,
@@ -578,5 +873,50 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
 }
+
+// ---- pinned host memory for the caller's buffers ------------------------------------------------------------
+int cabac_hip_host_alloc(size_t bytes, void **out) {
+  if (!out) return CABAC_HIP_ERR_INVALID;
+  *out = nullptr;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return CABAC_HIP_ERR_NOMEM;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_owned[p] = bytes ? bytes : 16;
+  *out = p;
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_host_free(void *p) {
+  if (!p) return CABAC_HIP_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!g_host_owned.erase(p)) return CABAC_HIP_ERR_INVALID;
+  }
+  return hipHostFree(p) == hipSuccess ? CABAC_HIP_OK : CABAC_HIP_ERR_HIP;
+}
+
+int cabac_hip_host_register(void *p, size_t bytes) {
+  if (!p || !bytes) return CABAC_HIP_ERR_INVALID;
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return CABAC_HIP_ERR_HIP;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_registered[p] = bytes;
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_host_unregister(void *p) {
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!g_host_registered.erase(p)) return CABAC_HIP_ERR_INVALID;
+  }
+  return hipHostUnregister(p) == hipSuccess ? CABAC_HIP_OK : CABAC_HIP_ERR_HIP;
+}
+
+int cabac_hip_host_is_pinned(const void *p, size_t bytes) { return host_is_pinned(p, bytes) ? 1 : 0; }
 
 }  // extern "C"

@@ -10,19 +10,21 @@ namespace cabac {
 
 hipError_t launch_ctx_init(hipStream_t st, uint32_t n_sub, const int32_t *qp, const uint32_t *init_id, uint32_t *state,
                            uint8_t *rate);
+// in_flight: the number of substreams on the device at the same time when this launch is one chunk of a batch whose
+// chunks run concurrently on several streams (0 = this launch is alone); the workgroup geometry follows the whole batch
 hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
-                         const uint16_t *records, uint8_t *bytes, cabac_substream_result *results);
+                         const uint16_t *records, uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
                          const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
-                         cabac_substream_result *results);
+                         cabac_substream_result *results, uint32_t in_flight = 0);
 
 // v4 "quad" kernels (cabac_kernels_v4.hip): four substreams per wave
 hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results);
 hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            uint8_t *bytes, cabac_substream_result *results);
+                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results);
+                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight = 0);
 
 // bit estimator (cabac_kernels_v4.hip)
 hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,

@@ -1153,12 +1153,12 @@ hipError_t launch_ctx_init(hipStream_t st, uint32_t n_sub, const int32_t *qp, co
 }
 
 hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
-                         const uint16_t *records, uint8_t *bytes, cabac_substream_result *results) {
+                         const uint16_t *records, uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
   // auto (measured): the two-wave quad encoder (v5) has the shortest per-substream chain at
   // every batch size tried (C2: 10, C3: 256, C4: 4 096, C5: 8 192 substreams)
-  if (kind == 5 || kind == 0) return launch_encode_v5(st, n_sub, desc, records, bytes, results);
+  if (kind == 5 || kind == 0) return launch_encode_v5(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 4) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
   if (kind == 1) {
     hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
@@ -1175,12 +1175,12 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
 
 hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
                          const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
-                         cabac_substream_result *results) {
+                         cabac_substream_result *results, uint32_t in_flight) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
   // auto: the quad decoder has the shortest per-substream chain at every batch size measured (C2: 10,
   // C3: 256, C4: 4 096 substreams), because it never crosses between the scalar and vector pipes
-  if (kind == 4 || kind == 5 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results);
+  if (kind == 4 || kind == 5 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight);
   if (kind == 1) {
     hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
   } else if (kind != 2) {

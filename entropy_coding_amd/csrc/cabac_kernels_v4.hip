@@ -1054,8 +1054,9 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
 }
 
 hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            uint8_t *bytes, cabac_substream_result *results) {
+                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
+  const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
   // Units (wave triples) per workgroup (CABAC_V5_UNITS overrides for experiments).  Four: the twelve waves of a
   // workgroup are dealt to the CU's four SIMDs in order, so that every SIMD gets one wave of each kind whatever ran
   // before.  Single-pair workgroups are a little faster when the dispatcher happens to spread them well (1.16
@@ -1068,7 +1069,7 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
     forced = e ? atoi(e) : 0;
   }
   // fewer pairs than SIMD quads (256 CUs x 4 pairs): single-pair workgroups, so that they spread over all CUs
-  const int upw = forced ? forced : (units >= 1024u ? 4 : 1);
+  const int upw = forced ? forced : (units_on_chip >= 1024u ? 4 : 1);
   if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
   else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(384), 0, st, n_sub, desc, records, bytes, results);
   else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
@@ -1076,9 +1077,9 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
 }
 
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results) {
+                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight) {
   const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  if (waves >= 1024u) {
+  if ((max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs >= 1024u) {
     hipLaunchKernelGGL(decode_kernel_v4<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, bytes, bins,
                        results);
   } else {

@@ -2,7 +2,10 @@
 #include "cabac_hip_host.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace EntropyCodingAMD {
 
@@ -16,6 +19,29 @@ void check_status(cabac_hip_ctx *ctx, int rc, const char *what) {
   fail(msg);
 }
 }  // namespace
+
+// ------------------------------------------------------------------ pinned mirrors
+namespace {
+std::atomic<bool> g_pinned{false};
+}
+void usePinnedMirrors(bool on) { g_pinned.store(on); }
+bool pinnedMirrors() { return g_pinned.load(); }
+
+void *hostAllocate(size_t bytes) {
+  void *p = nullptr;
+  if (g_pinned.load()) {
+    if (cabac_hip_host_alloc(bytes, &p) != CABAC_HIP_OK) throw std::bad_alloc();
+  } else {
+    p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+  }
+  return p;
+}
+
+void hostDeallocate(void *p) noexcept {
+  if (!p) return;
+  if (cabac_hip_host_free(p) == CABAC_HIP_ERR_INVALID) std::free(p);  // not from cabac_hip_host_alloc: heap memory
+}
 
 // ------------------------------------------------------------------ OutputBitstream
 void OutputBitstream::write(uint32_t uiBits, uint32_t uiNumberOfBits) {
@@ -177,11 +203,13 @@ void HipBatch::flush() {
     rec_total += p.records.size();
     byte_total += desc[s].byte_capacity;  // encode_bound is a multiple of 16
   }
-  std::vector<uint16_t> records(rec_total ? rec_total : 1);
+  RecordVector &records = m_stageRecords;
+  ByteVector &bytes = m_stageBytes;
+  if (records.size() < rec_total + 1) records.resize(rec_total + 1);
+  if (bytes.size() < byte_total + 1) bytes.resize(byte_total + 1);
   for (uint32_t s = 0; s < n; s++)
     if (!m_pending[s].records.empty())
       std::memcpy(records.data() + desc[s].rec_offset, m_pending[s].records.data(), m_pending[s].records.size() * 2);
-  std::vector<uint8_t> bytes(byte_total);
   std::vector<cabac_substream_result> res(n);
   int rc = cabac_hip_encode_batch(handle(), n, desc.data(), records.data(), rec_total, bytes.data(), byte_total,
                                   res.data());

@@ -37,11 +37,38 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
+// Pinned host / device mirrors of the reference's host buffers.  The FIFOs of the byte-stream containers below and the
+// record buffers of the recording encoders are std::vectors over HostAllocator: ordinary heap memory by default, and
+// page-locked memory mapped for the GPU's DMA engines (cabac_hip_host_alloc, cabac_hip.h) for every allocation made
+// while usePinnedMirrors(true) is in force — such buffers cross PCIe without a staging copy.  Switching it on needs a
+// GPU (allocations throw std::bad_alloc otherwise); a buffer remembers how it was allocated.
+void usePinnedMirrors(bool on);
+bool pinnedMirrors();
+void *hostAllocate(size_t bytes);
+void hostDeallocate(void *p) noexcept;
+
+template <class T>
+struct HostAllocator {
+  using value_type = T;
+  HostAllocator() = default;
+  template <class U>
+  HostAllocator(const HostAllocator<U> &) {}
+  T *allocate(size_t n) { return static_cast<T *>(hostAllocate(n * sizeof(T))); }
+  void deallocate(T *p, size_t) noexcept { hostDeallocate(p); }
+  template <class U>
+  bool operator==(const HostAllocator<U> &) const { return true; }
+  template <class U>
+  bool operator!=(const HostAllocator<U> &) const { return false; }
+};
+using ByteVector = std::vector<uint8_t, HostAllocator<uint8_t>>;
+using RecordVector = std::vector<uint16_t, HostAllocator<uint16_t>>;
+
+// ---------------------------------------------------------------------------------------------
 // Byte-stream containers (reference: common/bit_stream.hpp:16-97, :103-168).  Only the members the
 // bin codec and its callers use are mirrored; public data members keep the reference's names.
 class OutputBitstream {
 public:
-  std::vector<uint8_t> m_fifo;
+  ByteVector m_fifo;
   uint32_t m_num_held_bits = 0;
   uint8_t m_held_bits = 0;
 
@@ -53,8 +80,8 @@ public:
   void clear();
   int getNumBitsUntilByteAligned() const { return (8 - m_num_held_bits) & 0x7; }
   uint32_t getNumberOfWrittenBits() const { return uint32_t(m_fifo.size()) * 8 + m_num_held_bits; }
-  std::vector<uint8_t> &getFIFO() { return m_fifo; }
-  const std::vector<uint8_t> &getFIFO() const { return m_fifo; }
+  ByteVector &getFIFO() { return m_fifo; }
+  const ByteVector &getFIFO() const { return m_fifo; }
   uint8_t getHeldBits() const { return m_held_bits; }
   uint8_t *getByteStream() { return m_fifo.data(); }
   uint32_t getByteStreamLength() const { return uint32_t(m_fifo.size()); }
@@ -62,14 +89,14 @@ public:
 
 class InputBitstream {
 public:
-  std::vector<uint8_t> m_fifo;
+  ByteVector m_fifo;
   uint32_t m_fifo_idx = 0;
   uint32_t m_num_held_bits = 0;  // unread bits of the last byte taken from the FIFO: its low m_num_held_bits bits
   uint8_t m_held_bits = 0;
   uint32_t m_numBitsRead = 0;
 
-  std::vector<uint8_t> &getFifo() { return m_fifo; }
-  const std::vector<uint8_t> &getFifo() const { return m_fifo; }
+  ByteVector &getFifo() { return m_fifo; }
+  const ByteVector &getFifo() const { return m_fifo; }
   void read(uint32_t uiNumberOfBits, uint32_t &ruiBits);  // bit_stream.cpp:204-268 (throws "Exceeded FIFO size")
   uint32_t read(uint32_t numberOfBits) {
     uint32_t v;
@@ -188,7 +215,7 @@ public:
   // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned
   // in bytes[whole]) exactly as the reference's finish() leaves them.
   struct Pending {
-    std::vector<uint16_t> records;
+    RecordVector records;
     int qp = 0, initId = 0;
     uint64_t nCtx = 0, nEp = 0, nTrm = 0;
     OutputBitstream *sink = nullptr;
@@ -201,6 +228,10 @@ private:
   int m_device;
   cabac_hip_ctx *m_ctx = nullptr;
   std::vector<Pending> m_pending;
+  // the batch as the C ABI wants it (all records back to back, one byte slot per substream); kept between flushes, so
+  // that with pinned mirrors the page-locking is paid once
+  RecordVector m_stageRecords;
+  ByteVector m_stageBytes;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -265,14 +296,14 @@ public:
   // the window-size training helper estBits (cabac_writer.cpp:83-96), which is out of scope.
   unsigned getNumWrittenBits() override { throw Exception("getNumWrittenBits: not available from a recording encoder"); }
 
-  const std::vector<uint16_t> &records() const { return m_records; }
+  const RecordVector &records() const { return m_records; }
 
 private:
   void put(unsigned id, unsigned bin) { m_records.push_back(uint16_t(id | (bin ? CABAC_REC_BIN : 0u))); }
   HipBatch &m_batch;
   Mode m_mode;
   OutputBitstream *m_Bitstream = nullptr;
-  std::vector<uint16_t> m_records;
+  RecordVector m_records;
   int m_qp = 0, m_initId = 0;
 };
 

@@ -286,7 +286,27 @@ int cabac_hip_count_emulations_device(cabac_hip_ctx *ctx, uint32_t n_sub, const 
                                       const cabac_substream_result *d_results, const uint8_t *d_bytes,
                                       uint32_t *d_counts);
 
-/* ---- host-pointer convenience (synchronous; pinned staging inside) --- */
+/* ---- pinned host memory: the device mirrors of the reference's host buffers ------------------------------
+ * The reference keeps its byte strings in std::vector FIFOs (OutputBitstream::m_fifo, bit_stream.hpp:16-97;
+ * InputBitstream::m_fifo, :103-168; filled by write(), bit_stream.cpp:70-117) and its callers' bin records would live in
+ * ordinary heap memory too.  Memory obtained here is page-locked and mapped for the GPU's DMA engines: buffers in it
+ * cross PCIe without a staging copy (cabac_hip_encode_batch / _decode_batch detect it, as they detect memory pinned by
+ * cabac_hip_host_register or by anybody else, e.g. torch's pin_memory()).  The C++ shim's OutputBitstream /
+ * InputBitstream mirrors and the recording encoders allocate from here when EntropyCodingAMD::usePinnedMirrors(true)
+ * is set (host/cabac_hip_host.hpp).  No cabac_hip_ctx is needed; fails without a GPU.                              */
+int cabac_hip_host_alloc(size_t bytes, void **out);
+int cabac_hip_host_free(void *p);                    /* memory from cabac_hip_host_alloc only                      */
+int cabac_hip_host_register(void *p, size_t bytes);  /* pin an existing allocation in place (hipHostRegister)      */
+int cabac_hip_host_unregister(void *p);
+int cabac_hip_host_is_pinned(const void *p, size_t bytes); /* 1 if [p, p + bytes) is DMA-able where it lies         */
+
+/* ---- host-pointer entry points (synchronous) ---------------------------------------------------------------
+ * The whole trip host -> device -> host.  A batch whose substreams lie in ascending order in records[] / bytes[] is cut
+ * into chunks (about one per 1 024 substreams, at most 4); the H2D copy of chunk k+1, the kernel of chunk k and the D2H
+ * copy of chunk k-1 run on three kinds of HIP streams of the ctx.  Pinned caller memory (see above) is DMA'd where it
+ * lies; pageable memory goes through a ring of pinned 4 MiB blocks inside the ctx, block n+1 being copied by the host
+ * while block n is on the wire.  encode: the coded substreams are compacted on the device
+ * (cabac_hip_assemble_device's kernels) and leave in one copy per chunk, then are placed at bytes + byte_offset.    */
 int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
                            const uint16_t *records, uint64_t n_records_total, uint8_t *bytes,
                            uint64_t bytes_total, cabac_substream_result *results);

@@ -111,14 +111,14 @@ public:
   const EntropyCoding::BinStore *getBinStore() const override { return nullptr; }
   EntropyCoding::BinEncIf *getTestBinEncoder() const override { return nullptr; }
 
-  const std::vector<uint16_t> &records() const { return m_records; }
+  const EntropyCodingAMD::RecordVector &records() const { return m_records; }
 
 private:
   void put(unsigned id, unsigned bin) { m_records.push_back(uint16_t(id | (bin ? CABAC_REC_BIN : 0u))); }
   HipBatch &m_batch;
   Mode m_mode;
   Common::OutputBitstream *m_Bitstream = nullptr;
-  std::vector<uint16_t> m_records;
+  EntropyCodingAMD::RecordVector m_records;  // page-locked when EntropyCodingAMD::usePinnedMirrors(true) is set
   int m_qp = 0, m_initId = 0;
 };
 

@@ -46,7 +46,7 @@ long shim_record_ops(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, u
     enc.init(&bs);
     enc.reset(32, 2);
     apply_ops(enc, ops, n_ops);
-    const std::vector<uint16_t> &r = enc.records();
+    const auto &r = enc.records();
     if ((long)r.size() > cap) return -3;
     if (!r.empty()) memcpy(rec, r.data(), r.size() * 2);
     counts[1] = enc.getEP();
@@ -246,7 +246,7 @@ long shim_estimate_segments(const uint32_t *ops, const long *seg_end, const int 
       begin = seg_end[i];
       if (!record_only) costs[i] = est.getEstFracBits();
     }
-    const std::vector<uint16_t> &r = est.records();
+    const auto &r = est.records();
     if (rec) {
       if ((long)r.size() > cap) return -3;
       if (!r.empty()) memcpy(rec, r.data(), r.size() * 2);
@@ -284,7 +284,7 @@ int shim_residual_round_trip(int n_jobs, const int *job_first, const int *geom, 
     HipBatch batch(0);
     std::vector<HipBatch::ParseJob> jobs(n_jobs);
     std::vector<OutputBitstream> streams(n_jobs);
-    std::vector<std::vector<uint8_t>> bytes(n_jobs);
+    std::vector<ByteVector> bytes(n_jobs);
     const int32_t *cin = coeff_in;
     for (int j = 0; j < n_jobs; j++) {
       std::vector<HipBatch::ResidualBlock> blocks;
