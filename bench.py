@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--dec-variant", type=int, default=0)
     ap.add_argument("--no-residual", action="store_true", help="skip the residual-binariser leg (C4, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -147,6 +148,75 @@ def cpu_baseline(cfg, desc, records, budget_s):
         "one_thread": {"value": round(2 * bins1 / (enc1 + dec1) / 1e6, 2), "cores": 1,
                        "encode_mbins_s": round(bins1 / enc1 / 1e6, 2), "decode_mbins_s": round(bins1 / dec1 / 1e6, 2)},
     }
+
+
+def end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins, reps=3):
+    """The host-pointer path, PCIe included: cabac_hip_encode_batch / cabac_hip_decode_batch from host memory to host
+    memory (chunked H2D / kernel / D2H on separate streams, compacted output, see cabac_hip.h), once with the caller's
+    buffers in pinned memory (cabac_hip_host_alloc — what the shim's mirrors use under usePinnedMirrors) and once in
+    pageable memory (through the library's pinned bounce ring).  Wall time of the synchronous call, best of `reps`."""
+    from entropy_coding_amd import capi
+    out = {}
+    want_bins = (records >> 15).astype(np.uint8)
+    ref_bytes = None
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            keep = [capi.PinnedArray(records.shape, np.uint16), capi.PinnedArray((bytes_total,), np.uint8),
+                    capi.PinnedArray((len(records),), np.uint8)]
+            h_rec, h_out, h_bins = (k.array for k in keep)
+            h_rec[:] = records
+        else:
+            keep = []
+            h_rec, h_out, h_bins = records, np.zeros(bytes_total, np.uint8), np.zeros(len(records), np.uint8)
+        t_enc, t_dec = [], []
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            _, res = hip.encode_batch(desc, h_rec, bytes_total, out=h_out)
+            t1 = time.perf_counter()
+            t_enc.append(t1 - t0)
+        # decode input as a decoder has it: the coded substreams packed (16-byte aligned slots), not the encoder's
+        # worst-case slots
+        nb = (res["n_bits"].astype(np.int64) + 7) // 8
+        ddesc = desc.copy()
+        ddesc["byte_capacity"] = nb
+        slot = (nb + 15) // 16 * 16
+        ddesc["byte_offset"] = np.concatenate([[0], np.cumsum(slot)[:-1]])
+        in_total = int(slot.sum())
+        if kind == "pinned":
+            keep.append(capi.PinnedArray((in_total,), np.uint8))
+            h_in = keep[-1].array
+        else:
+            h_in = np.zeros(in_total, np.uint8)
+        for s in range(len(desc)):
+            o, q, n = int(desc["byte_offset"][s]), int(ddesc["byte_offset"][s]), int(nb[s])
+            h_in[q:q + n] = h_out[o:o + n]
+        for _ in range(reps + 1):
+            t2 = time.perf_counter()
+            _, rd = hip.decode_batch(ddesc, h_rec, h_in, bins=h_bins)
+            t3 = time.perf_counter()
+            t_dec.append(t3 - t2)
+        ok = not res["flags"].any() and not rd["flags"].any()
+        live = np.zeros(len(records), bool)
+        for s in range(len(desc)):
+            o, n = int(desc["rec_offset"][s]), int(desc["n_records"][s])
+            live[o:o + n] = True
+        ok = ok and bool(np.array_equal(h_bins[live], want_bins[live]))
+        coded = np.concatenate([h_out[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + (int(res["n_bits"][s]) + 7) // 8]
+                                for s in range(0, len(desc), max(len(desc) // 256, 1))])
+        if ref_bytes is None:
+            ref_bytes = coded.copy()
+        ok = ok and bool(np.array_equal(coded, ref_bytes))
+        e, d = min(t_enc[1:]), min(t_dec[1:])
+        out[kind] = {"encode_ms": round(e * 1e3, 3), "decode_ms": round(d * 1e3, 3),
+                     "encode_mbins_s": round(n_bins / e / 1e6, 1), "decode_mbins_s": round(n_bins / d / 1e6, 1),
+                     "mbins_s": round(2 * n_bins / (e + d) / 1e6, 1), "round_trip": bool(ok)}
+        for k in keep:
+            k.close()
+    h2d_enc = 2 * n_bins + 32 * len(desc)
+    out["pcie_bytes"] = {"encode_h2d": h2d_enc, "encode_d2h": int(nb.sum()) + 16 * len(desc), "decode_h2d": h2d_enc + in_total,
+                         "decode_d2h": int(len(records))}
+    out["what"] = "cabac_hip_encode_batch + cabac_hip_decode_batch, host memory to host memory, wall time of the calls"
+    return out
 
 
 def residual_leg(hip, n_tiles, unique=256, reps=4):
@@ -524,6 +594,11 @@ def main():
             line["residual"] = residual
         if gather_ms is not None:
             line["sizes_allgather_ms"] = round(gather_ms, 3)
+        if world == 1 and not args.no_end_to_end:
+            try:
+                line["end_to_end"] = end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins)
+            except Exception as e:  # the headline line must not depend on this leg
+                line["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, desc, records, args.cpu_seconds)
         if not line["hash_match"]:

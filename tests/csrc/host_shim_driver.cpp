@@ -66,8 +66,14 @@ long shim_record_ops(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, u
 // out: streams packed back to back at out_off[s]; n_bits[s] = getNumberOfWrittenBits().
 int shim_encode_streams(int n_streams, const uint32_t *ops, const long *op_off, const int *qp, const int *init_id,
                         int mode, int flags, uint8_t *out, const long *out_off, uint32_t *n_bits) {
+  // flags bit2: pinned mirrors — FIFOs, record buffers and the batch's staging are page-locked from here on
+  struct PinGuard {
+    explicit PinGuard(bool on) { usePinnedMirrors(on); }
+    ~PinGuard() { usePinnedMirrors(false); }
+  } pin((flags & 4) != 0);
   try {
     HipBatch batch(0);
+    if (flags & 4) batch.handle();  // pinned allocation needs the device
     std::vector<std::unique_ptr<BinEncoderHip>> enc;
     std::vector<OutputBitstream> bs(n_streams);
     for (int s = 0; s < n_streams; s++) {

@@ -1,0 +1,128 @@
+"""The host-pointer path of the C ABI (cabac_hip_encode_batch / cabac_hip_decode_batch): pinned caller memory DMA'd
+where it lies, pageable memory through the pinned bounce ring, batches cut into chunks that overlap H2D / kernel / D2H
+on separate streams, coded substreams compacted on the device and copied back once per chunk.  Whatever the route, the
+bytes, bit counts and flags are the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from entropy_coding_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _ragged_batch(rng, n_sub, max_len):
+    lens = [0, 1, 2, 17][: min(4, n_sub)] + [int(x) for x in rng.integers(0, max_len, size=max(n_sub - 4, 0))]
+    recs = [H.random_records(rng, max(n - 1, 0), end_trm=(n > 0)) for n in lens]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=n_sub), rng.integers(0, 3, size=n_sub),
+                              H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    return desc, records, total
+
+
+def _check_against_oracle(hip, desc, records, total, pinned):
+    orc = H.load_oracle()
+    keep = []
+    if pinned:
+        keep = [capi.PinnedArray(records.shape, np.uint16), capi.PinnedArray((max(total, 1),), np.uint8),
+                capi.PinnedArray((max(len(records), 1),), np.uint8)]
+        h_rec, h_out, h_bins = (k.array for k in keep)
+        h_rec[:] = records
+        h_out[:] = 0
+        assert capi.host_is_pinned(h_rec) and capi.host_is_pinned(h_out[5:100])
+    else:
+        h_rec, h_out, h_bins = records, np.zeros(max(total, 1), np.uint8), np.zeros(max(len(records), 1), np.uint8)
+        assert not capi.host_is_pinned(h_rec)
+    out_g, res_g = hip.encode_batch(desc, h_rec, total, check=False, out=h_out)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    assert np.array_equal(res_g["n_bits"], res_o["n_bits"]) and np.array_equal(res_g["flags"], res_o["flags"])
+    for s in range(len(desc)):
+        o, nb = int(desc["byte_offset"][s]), (int(res_o["n_bits"][s]) + 7) // 8
+        assert np.array_equal(out_g[o:o + nb], out_o[o:o + nb]), s
+    dd = desc.copy()
+    dd["byte_capacity"] = (res_o["n_bits"] + 7) // 8
+    bins_g, rd = hip.decode_batch(dd, h_rec, h_out, check=False, bins=h_bins)
+    bins_o, ro = orc.decode_batch(dd, records, out_o)
+    assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"])
+    assert np.array_equal(bins_g[: len(records)], bins_o) and np.array_equal(bins_o, (records >> 15).astype(np.uint8))
+    for k in keep:
+        k.close()
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 2, 3, 8])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_path_matches_oracle(chunks, pinned):
+    """5 000 ragged substreams (empty ones among them) through every chunk count, from pinned and from pageable memory."""
+    os.environ["CABAC_HIP_CHUNKS"] = str(chunks)   # read when the ctx sets up its streams
+    try:
+        hip = capi.CabacHip(0)
+        rng = np.random.default_rng(1000 + chunks)
+        desc, records, total = _ragged_batch(rng, 5000, 1500)
+        _check_against_oracle(hip, desc, records, total, pinned)
+        # the same ctx again with another batch: staging buffers and rings are reused
+        desc, records, total = _ragged_batch(rng, 700, 9000)
+        _check_against_oracle(hip, desc, records, total, pinned)
+        hip.close()
+    finally:
+        del os.environ["CABAC_HIP_CHUNKS"]
+
+
+def test_host_path_large_pageable_batch_uses_the_whole_ring():
+    """More than ring depth x block size in every direction (records 40 MB, bins 20 MB) from pageable memory."""
+    hip = capi.CabacHip(0)
+    rng = np.random.default_rng(5)
+    n_sub = 4096
+    recs = H.random_records(rng, 4999)
+    records = np.tile(recs, n_sub)
+    desc, total = H.make_desc([len(recs)] * n_sub, [30] * n_sub, [2] * n_sub, H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    out, res = hip.encode_batch(desc, records, total)
+    one, nbits = H.load_oracle().encode_records(recs, 30, 2, 3)
+    assert (res["n_bits"] == nbits).all() and not res["flags"].any()
+    for s in range(0, n_sub, 113):
+        o = int(desc["byte_offset"][s])
+        assert np.array_equal(out[o:o + len(one)], one)
+    dd = desc.copy()
+    dd["byte_capacity"] = (res["n_bits"] + 7) // 8
+    bins, rd = hip.decode_batch(dd, records, out)
+    assert not rd["flags"].any() and np.array_equal(bins, (records >> 15).astype(np.uint8))
+    hip.close()
+
+
+def test_host_path_unordered_descriptors_fall_back_to_one_chunk():
+    os.environ["CABAC_HIP_CHUNKS"] = "4"
+    try:
+        hip = capi.CabacHip(0)
+        rng = np.random.default_rng(8)
+        desc, records, total = _ragged_batch(rng, 3000, 800)
+        perm = rng.permutation(len(desc))
+        _check_against_oracle(hip, desc[perm].copy(), records, total, False)
+        hip.close()
+    finally:
+        del os.environ["CABAC_HIP_CHUNKS"]
+
+
+def test_host_memory_api():
+    L = capi.load_library()
+    a = capi.PinnedArray((1000,), np.uint16)
+    assert capi.host_is_pinned(a.array) and capi.host_is_pinned(a.array[10:20])
+    plain = np.zeros(1 << 16, np.uint8)
+    assert not capi.host_is_pinned(plain)
+    assert L.cabac_hip_host_free(capi.vp(plain.ctypes.data)) == -2          # not from cabac_hip_host_alloc
+    assert L.cabac_hip_host_register(capi.vp(plain.ctypes.data), plain.nbytes) == 0
+    assert capi.host_is_pinned(plain)
+    hip = capi.CabacHip(0)                                                    # a registered buffer is DMA'd in place
+    rec = H.random_records(np.random.default_rng(1), 3000)
+    buf = plain[: 2 * len(rec)].view(np.uint16)
+    buf[:] = rec
+    desc, total = H.make_desc([len(rec)], [32], [2], H.SUB_FINISH)
+    out, res = hip.encode_batch(desc, buf, total)
+    want, nbits = H.load_oracle().encode_records(rec, 32, 2, 1)
+    assert int(res["n_bits"][0]) == nbits and np.array_equal(out[: len(want)], want)
+    hip.close()
+    assert L.cabac_hip_host_unregister(capi.vp(plain.ctypes.data)) == 0
+    assert L.cabac_hip_host_unregister(capi.vp(plain.ctypes.data)) == -2
+    assert not capi.host_is_pinned(plain)
+    a.close()

@@ -230,11 +230,11 @@ def test_shim_encode_matches_oracle(drv, mode):
     rng = np.random.default_rng(70 + mode)
     op_list = [H.random_ops(rng, int(n), ctx_frac=0.6, end_trm=False) for n in rng.integers(0, 1500, size=12)]
     qps, ids = rng.integers(0, 64, size=12), rng.integers(0, 3, size=12)
-    for flags in (0, 2):
+    for flags in (0, 2, 4, 6):     # bit1: writeByteAlignment afterwards; bit2: pinned mirrors (usePinnedMirrors)
         got, nbits = _encode_streams(drv, op_list, qps, ids, mode, flags)
         for s, ops in enumerate(op_list):
             full = np.concatenate([ops.reshape(-1, 4), np.array([[H.OP_TRM, 1, 0, 0]], np.uint32)])
-            want, wbits, _ = orc.encode_ops(full, int(qps[s]), int(ids[s]), 1 | flags)
+            want, wbits, _ = orc.encode_ops(full, int(qps[s]), int(ids[s]), 1 | (flags & 2))
             assert wbits == nbits[s] and np.array_equal(got[s], want), s
 
 
