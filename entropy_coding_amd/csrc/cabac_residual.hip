@@ -29,51 +29,11 @@
 #include "cabac_device.h"
 #include "cabac_hip.h"
 #include "cabac_kernels.h"
+#include "cabac_scan.h"
 
 namespace cabac {
 
 namespace {
-
-// k-th position of the up-right diagonal scan of a bw x bh rectangle, packed x | y << 4.
-struct DiagLut {
-  uint8_t grid[4][4][64];   // [log2 groups per row][log2 groups per column][group index]
-  uint8_t in_cg[5][5][16];  // [log2 group width][log2 group height][position in group]
-};
-
-constexpr void fill_diag(uint8_t *out, int bw, int bh) {
-  int k = 0;
-  for (int d = 0; d <= bw + bh - 2; d++) {
-    const int y_hi = d < bh - 1 ? d : bh - 1;
-    const int y_lo = d - (bw - 1) > 0 ? d - (bw - 1) : 0;
-    for (int y = y_hi; y >= y_lo; y--, k++) out[k] = (uint8_t)((d - y) | (y << 4));
-  }
-}
-
-constexpr DiagLut make_lut() {
-  DiagLut t{};
-  for (int a = 0; a < 4; a++)
-    for (int b = 0; b < 4; b++) fill_diag(t.grid[a][b], 1 << a, 1 << b);
-  for (int a = 0; a < 5; a++)
-    for (int b = 0; b + a < 5; b++) fill_diag(t.in_cg[a][b], 1 << a, 1 << b);
-  return t;
-}
-
-__constant__ DiagLut c_diag = make_lut();
-
-// g_goRiceParsCoeff (rom.cpp:27-29) as thresholds: 0 below 7, 1 below 14, 2 below 28, else 3
-__device__ __forceinline__ uint32_t rice_of(int sum_abs, int base_level) {
-  int v = sum_abs - 5 * base_level;
-  v = v < 0 ? 0 : v;
-  return (uint32_t)(v >= 7) + (uint32_t)(v >= 14) + (uint32_t)(v >= 28);
-}
-
-__device__ __forceinline__ uint32_t group_idx(uint32_t p) {  // g_groupIdx, rom.cpp:21-25
-  const uint32_t fl = 31u - (uint32_t)__builtin_clz(p | 1u);
-  return p < 4u ? p : 2u * fl + ((p >> (fl - 1u)) & 1u);
-}
-__device__ __forceinline__ uint32_t min_in_group(uint32_t g) {  // g_minInGroup, rom.cpp:18-19
-  return g < 4u ? g : (2u + (g & 1u)) << ((g >> 1) - 1u);
-}
 
 template <int N>
 __device__ __forceinline__ uint32_t row_shl(uint32_t v) {  // lane l <- lane l + N of the same row, 0 outside

@@ -239,6 +239,7 @@ typedef struct cabac_tu_desc {
 
 /* d_info[t] (may be NULL): scanPosLast in bits 15..0, what residual_coding records in its CUCtx argument */
 #define CABAC_TU_INFO_LAST_MASK 0xFFFFu
+#define CABAC_TU_INFO_TS 0x20000u            /* residual parser: the block was parsed as transform skip (mtsIdx = MTS_SKIP) */
 #define CABAC_TU_INFO_MTS_VIOLATION 0x10000u /* a coded luma group with cgPosX > 3 or cgPosY > 3 (cabac_writer.cpp:2519-2522) */
 #define CABAC_TU_INFO_EMPTY 0x80000000u      /* all coefficients zero: the reference throws; no records     */
 #define CABAC_TU_INFO_BAD_DESC 0x40000000u   /* log2 size > 6 or channel > 1: no records                    */

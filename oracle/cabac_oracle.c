@@ -1322,27 +1322,134 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
 }
 
 /* ---------------------------------------------------------------- residual parser (decoder side)
- * Restates CABACReader::residual_coding (cabac_reader.cpp:2647-2735), last_sig_coeff (:2865-2938) and
- * residual_coding_subblock (:2946-3128) for regular residual coding: the context of every bin follows from the
- * coefficients decoded so far, so no bin/context sequence is supplied.  One substream = n_tu blocks in order, then
- * (finish != 0) encodeBinTrm(1) / finish() are checked.  coeff_out receives each block at tus[t].coeff_offset (raster,
- * stride = width; only the coded region of a 64-wide/tall block is written).
- * Returns 0; -2 unsupported block (transform skip, bad size); -4 read past the end; -5 missing terminate bin / stop
- * pattern. */
-static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff) {
+ * Restates CABACReader::residual_coding (cabac_reader.cpp:2647-2735), ts_flag (:2737-2752), last_sig_coeff (:2865-2938),
+ * residual_coding_subblock (:2946-3128), residual_codingTS (:3130-3152) and residual_coding_subblockTS (:3154-3339): the
+ * context of every bin follows from the coefficients decoded so far, so no bin/context sequence is supplied.  One
+ * substream = n_tu blocks in order, then (finish != 0) encodeBinTrm(1) / finish() are checked.  coeff_out receives each
+ * block at tus[t].coeff_offset (raster, stride = width; only the coded region of a 64-wide/tall block is written).
+ * A block with CABAC_TU_TS_FLAG has its transform_skip_flag in the stream and is parsed as that bin says (the
+ * descriptor's CABAC_TU_TRANSFORM_SKIP bit is then ignored); without it the descriptor's bit decides (BDPCM blocks: the
+ * reference infers the flag).  info[t] (may be NULL): scanPosLast | CABAC_TU_INFO_MTS_VIOLATION for a regular block,
+ * CABAC_TU_INFO_TS for a block parsed as transform skip.
+ * Returns 0; -2 unsupported block (bad size, transform skip wider/taller than 32); -4 read past the end; -5 missing
+ * terminate bin / stop pattern. */
+static int parse_block_ts(bin_dec *d, const blk_geom *g, const uint32_t *scan, int bdpcm, int max_log2, int32_t *coeff) {
+#define SX(p) ((int)(scan[p] & 0xffff))
+#define SY(p) ((int)(scan[p] >> 16))
+#define AT(x, y) (coeff[(y) * g->w + (x)])
+  const int n_cg = (g->w * g->h) >> g->cg_l2, cg_size = 1 << g->cg_l2;
+  uint8_t cg_sig[64];
+  int n_sig = 0;
+  memset(cg_sig, 0, sizeof cg_sig);
+  int budget = (g->w * g->h * 7) >> 2; /* cabac_reader.cpp:3136-3137 */
+  for (int cg = 0; cg < n_cg; cg++) {
+    const int lo = cg << g->cg_l2, hi = lo + cg_size - 1;
+    const int cgx = SX(lo) >> g->cgw_l2, cgy = SY(lo) >> g->cgh_l2;
+    int sig = cg == n_cg - 1 && n_sig == 0; /* :3203: the last group of a block without any significant group */
+    if (!sig) {
+      const int left = cgx > 0 ? cg_sig[cgy * g->wg + cgx - 1] : 0, above = cgy > 0 ? cg_sig[(cgy - 1) * g->wg + cgx] : 0;
+      sig = (int)dec_bin(d, CABAC_CTX_TS_SIG_COEFF_GROUP + (unsigned)(left + above));
+    }
+    if (!sig) continue;
+    cg_sig[cgy * g->wg + cgx] = 1;
+    n_sig++;
+    int n_nz = 0, last1 = -1, last2 = -1, p;
+    int nz_pos[16];
+    unsigned sign_pattern = 0;
+    for (p = lo; p <= hi && budget >= 4; p++) { /* pass 1: sig, sign, greater-1, parity (:3222-3271) */
+      const int x = SX(p), y = SY(p);
+      const int left = x > 0 ? AT(x - 1, y) : 0, above = y > 0 ? AT(x, y - 1) : 0;
+      const int n_nb = (left != 0) + (above != 0);
+      unsigned sf = (!n_nz && p == hi);
+      if (!sf) {
+        sf = dec_bin(d, CABAC_CTX_TS_SIG_FLAG + (unsigned)n_nb);
+        budget--;
+      }
+      if (sf) {
+        const int sl = (left > 0) - (left < 0), sa = (above > 0) - (above < 0);
+        unsigned sctx = ((sl == 0 && sa == 0) || sl * sa < 0) ? 0u : (sl >= 0 && sa >= 0) ? 1u : 2u;
+        if (bdpcm) sctx += 3;
+        const unsigned sign = dec_bin(d, CABAC_CTX_TS_RESIDUAL_SIGN + sctx);
+        sign_pattern += sign << n_nz;
+        nz_pos[n_nz++] = p;
+        const unsigned g1 = dec_bin(d, CABAC_CTX_TS_LRG1_FLAG + (unsigned)(bdpcm ? 3 : n_nb));
+        budget -= 2;
+        unsigned par = 0;
+        if (g1) {
+          par = dec_bin(d, CABAC_CTX_TS_PAR_FLAG);
+          budget--;
+        }
+        AT(x, y) = (sign ? -1 : 1) * (int32_t)(1 + par + g1);
+      }
+      last1 = p;
+    }
+    for (p = lo; p <= hi && budget >= 4; p++) { /* pass 2: greater-than-3/5/7/9 flags on the magnitudes (:3276-3297) */
+      int32_t *c = &AT(SX(p), SY(p));
+      if (*c < 0) *c = -*c;
+      for (int cut = 2; cut <= 8; cut += 2)
+        if (*c >= cut) {
+          *c += (int32_t)(dec_bin(d, CABAC_CTX_TS_GTX_FLAG + (unsigned)(cut >> 1)) << 1);
+          budget--;
+        }
+      last2 = p;
+    }
+    for (p = lo; p <= hi; p++) { /* pass 3: remainders, bypass-coded levels with their signs, level un-mapping (:3299-3329) */
+      const int x = SX(p), y = SY(p);
+      int32_t *c = &AT(x, y);
+      const int cut = p <= last2 ? 10 : p <= last1 ? 2 : 0;
+      if (*c < 0) *c = -*c;
+      if (*c >= cut) {
+        const int32_t rem = (int32_t)dec_rem_abs(d, 1, 5, max_log2);
+        *c += p <= last1 ? rem << 1 : rem;
+        if (*c && p > last1) {
+          sign_pattern += dec_ep(d) << n_nz;
+          nz_pos[n_nz++] = p;
+        }
+      }
+      if (!bdpcm && cut && *c > 0) { /* decDeriveModCoeff, context_modelling.hpp:367-384 */
+        int left = x > 0 ? AT(x - 1, y) : 0, above = y > 0 ? AT(x, y - 1) : 0;
+        if (left < 0) left = -left;
+        if (above < 0) above = -above;
+        const int pred = left > above ? left : above;
+        *c = (*c == 1 && pred > 0) ? pred : *c - (*c <= pred);
+      }
+    }
+    for (int k = 0; k < n_nz; k++) { /* signs (:3332-3338) */
+      int32_t *c = &AT(SX(nz_pos[k]), SY(nz_pos[k]));
+      if (sign_pattern & 1) *c = -*c;
+      sign_pattern >>= 1;
+    }
+  }
+#undef SX
+#undef SY
+#undef AT
+  return 0;
+}
+
+static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff, uint32_t *info) {
   const int lw = tu->log2_width, lh = tu->log2_height, chroma = tu->channel;
   const unsigned flags = tu->flags;
   const int max_log2 = tu->max_log2_tr_range ? tu->max_log2_tr_range : 15;
-  if (lw > 6 || lh > 6 || chroma > 1 || (flags & CABAC_TU_TRANSFORM_SKIP)) return -2;
+  if (lw > 6 || lh > 6 || chroma > 1) return -2;
   blk_geom g;
   blk_geom_init(&g, lw, lh);
+  /* ts_flag, cabac_reader.cpp:2737-2752 */
+  unsigned ts = (flags & CABAC_TU_TRANSFORM_SKIP) != 0;
+  if (flags & CABAC_TU_TS_FLAG) ts = dec_bin(d, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma));
+  if (ts && (lw > 5 || lh > 5)) return -2;
   uint32_t *scan = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(g.w * g.h));
   orc_scan_order(lw, lh, scan);
 #define SX(p) ((int)(scan[p] & 0xffff))
 #define SY(p) ((int)(scan[p] >> 16))
   const int we = g.w < 32 ? g.w : 32, he = g.h < 32 ? g.h : 32;
   memset(coeff, 0, sizeof(int32_t) * (size_t)(g.w * g.h)); /* the reader requires a zeroed block (cabac_reader.cpp:2950) */
-  if (flags & CABAC_TU_TS_FLAG) (void)dec_bin(d, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma)); /* must be 0 for these blocks */
+  if (ts) {
+    const int rc_ts = parse_block_ts(d, &g, scan, (flags & CABAC_TU_BDPCM) != 0, max_log2, coeff);
+    free(scan);
+    if (info) *info = CABAC_TU_INFO_TS;
+    return rc_ts ? rc_ts : d->underrun ? -4 : 0;
+  }
+  uint32_t info_bits = 0;
 
   /* last significant position */
   static const uint8_t luma_off[7] = {0, 0, 0, 3, 6, 10, 15};
@@ -1363,6 +1470,7 @@ static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff) {
   int last = 0;
   for (; last < g.w * g.h - 1; last++)
     if (SX(last) == (int)px && SY(last) == (int)py) break;
+  info_bits = (uint32_t)last;
 
   const unsigned trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u;
   int state = 0, budget = (we * he * 28) >> 4;
@@ -1380,6 +1488,7 @@ static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff) {
     }
     if (!sig) continue;
     cg_sig[cgy * g.wg + cgx] = 1;
+    if (!chroma && (cgx > 3 || cgy > 3)) info_bits |= CABAC_TU_INFO_MTS_VIOLATION; /* cabac_reader.cpp:2729-2732 */
     const int first = cg == last_cg ? last : hi;
     const int infer = cg == last_cg ? last : (cg != 0 ? lo : -1);
     int n_nz = 0, first_nz = first, last_nz = -1, p;
@@ -1459,11 +1568,12 @@ static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff) {
 #undef SX
 #undef SY
   free(scan);
+  if (info) *info = info_bits;
   return d->underrun ? -4 : 0;
 }
 
 int orc_residual_decode(const uint8_t *in, long n_in, int qp, int init_id, const void *tus_, long n_tu, int finish,
-                        int32_t *coeff_out, uint32_t *n_bits_read) {
+                        int32_t *coeff_out, uint32_t *n_bits_read, uint32_t *info) {
   const cabac_tu_desc *tus = (const cabac_tu_desc *)tus_;
   bin_dec d;
   memset(&d, 0, sizeof d);
@@ -1472,7 +1582,7 @@ int orc_residual_decode(const uint8_t *in, long n_in, int qp, int init_id, const
   ctx_store_init(&d.ctx, qp, init_id);
   dec_start(&d);
   for (long t = 0; t < n_tu; t++) {
-    const int rc = parse_block(&d, &tus[t], coeff_out + tus[t].coeff_offset);
+    const int rc = parse_block(&d, &tus[t], coeff_out + tus[t].coeff_offset, info ? &info[t] : NULL);
     if (rc) return rc;
   }
   int rc = 0;

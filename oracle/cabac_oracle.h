@@ -93,7 +93,7 @@ long orc_scan_order(int log2_width, int log2_height, uint32_t *out);
  * finish: expect TRM(1) and the stop pattern after the last block.  Returns 0, -2 unsupported block, -4 read past the
  * end, -5 missing terminate bin / stop pattern. */
 int orc_residual_decode(const uint8_t *in, long n_in, int qp, int init_id, const void *tus, long n_tu, int finish,
-                        int32_t *coeff_out, uint32_t *n_bits_read);
+                        int32_t *coeff_out, uint32_t *n_bits_read, uint32_t *info);
 
 #ifdef __cplusplus
 }

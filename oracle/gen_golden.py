@@ -206,12 +206,54 @@ def residual_parse(ref):
             recs.append(ref.residual_records(c, ch, flags)[0])
         rec = np.concatenate(recs + [np.array([0x81FF], np.uint16)])
         data, _ = ref.encode_records(rec, qp, 2, 3)
-        rc, dec, nbits = ref.residual_decode(data, qp, metas)
+        rc, dec, nbits, rinfo = ref.residual_decode(data, qp, metas, with_info=True)
         assert rc == 0
         out["s%d_meta" % s] = np.array(metas, np.int32)
         out["s%d_qp" % s] = np.array([qp, nbits], np.int64)
         out["s%d_bytes" % s] = data
         out["s%d_coeff" % s] = np.concatenate([d.ravel() for d in dec]).astype(np.int32)
+        out["s%d_refinfo" % s] = np.asarray(rinfo, np.int32)
+    # substreams that mix regular and transform-skip residual coding (residual_codingTS, cabac_reader.cpp:3130-3339):
+    # transform_skip_flag in the stream (0 or 1), transform skip without a coded flag, BDPCM; refinfo holds what the reader
+    # left in mtsIdx / CUCtx per block (ref_residual_decode)
+    rng = np.random.default_rng(0x75A45E)
+    sizes = [1, 2, 4, 8, 16, 32]
+    n_ts = 16
+    for s in range(n_sub, n_sub + n_ts):
+        qp = int(rng.integers(0, 64))
+        metas, recs = [], []
+        for k in range(int(rng.integers(3, 14))):
+            kind = int(rng.integers(0, 5))
+            slice_fl = int(rng.integers(0, 4))          # dependent quantisation / sign hiding, per block
+            ch = int(rng.integers(0, 2))
+            if kind < 2:
+                w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 32), (8, 4), (2, 8), (16, 4)][int(rng.integers(0, 8))]
+                if kind == 1 and max(w, h) > 32:
+                    w, h = 32, 32
+                c = H.random_block(rng, w, h, density=float(rng.choice([0.1, 0.5, 1.0])), big=float(rng.choice([0.0, 0.2])))
+                fl = slice_fl | (H.TU_TS_FLAG if kind == 1 else 0)
+            else:
+                w, h = sizes[int(rng.integers(0, 6))], sizes[int(rng.integers(0, 6))]
+                if w * h == 1:
+                    w = 2
+                mode = int(rng.integers(0, 4))
+                c = ((rng.random((h, w)) < [0.3, 1.0, 0.8, 0.05][mode]) *
+                     rng.integers(-[4, 40, 3, 3000][mode], [4, 40, 3, 3000][mode] + 1, (h, w))).astype(np.int32)
+                if not c.any():
+                    c[0, 0] = -1
+                fl = slice_fl | H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, 0, H.TU_BDPCM][kind - 2]
+            metas.append((w, h, ch, fl))
+            recs.append(ref.residual_records(c, ch, fl)[0])
+        rec = np.concatenate(recs + [np.array([0x81FF], np.uint16)])
+        data, _ = ref.encode_records(rec, qp, 2, 3)
+        rc, dec, nbits, rinfo = ref.residual_decode(data, qp, metas, with_info=True)
+        assert rc == 0
+        out["s%d_meta" % s] = np.array(metas, np.int32)
+        out["s%d_qp" % s] = np.array([qp, nbits], np.int64)
+        out["s%d_bytes" % s] = data
+        out["s%d_coeff" % s] = np.concatenate([d.ravel() for d in dec]).astype(np.int32)
+        out["s%d_refinfo" % s] = np.asarray(rinfo, np.int32)
+    n_sub += n_ts
     out["n_sub"] = np.array([n_sub], np.int32)
     path = os.path.join(GOLD, "residual_parse.npz")
     np.savez_compressed(path, **out)

@@ -553,10 +553,14 @@ long ref_scan_order(int width, int height, uint32_t *out) {
 }
 
 // The reference's own CABACReader::residual_coding (cabac_reader.cpp:2647-2735) on n blocks in one substream: sizes
-// wh[2i], wh[2i+1], component comp[i] (rig flags as ref_residual_records), coefficients written back to back into
-// coeff_out.  finish: then decodeBinTrm() must give 1 and finish() is called.
+// wh[2i], wh[2i+1], component comp[i], rig flags (as ref_residual_records) rig_flags for every block or, if block_flags
+// is given, block_flags[i]; coefficients written back to back into coeff_out.  With transform skip enabled in the rig
+// (bit2) the reader takes transform_skip_flag from the stream (ts_flag, :2737-2752) unless BDPCM (bit5) infers it.
+// info (may be NULL), 5 ints per block from a fresh CUCtx: {mtsIdx == MTS_SKIP after the call, violatesLfnstConstrained
+// luma | chroma << 1, lfnstLastScanPos, violatesMtsCoeffConstraint, mtsLastScanPos}.
+// finish: then decodeBinTrm() must give 1 and finish() is called.
 long ref_residual_decode(int n, const int *wh, const int *comp, int rig_flags, const uint8_t *in, long n_in, int qp,
-                         int finish, int32_t *coeff_out, uint32_t *n_bits_read) {
+                         int finish, int32_t *coeff_out, uint32_t *n_bits_read, const int *block_flags, int32_t *info) {
   try {
     static ResidualRig rig;
     BinDecoder_Std dec;
@@ -565,17 +569,24 @@ long ref_residual_decode(int n, const int *wh, const int *comp, int rig_flags, c
     CABACReader r(dec);
     r.initBitstream(&ib);
     dec.reset(qp, 2);
-    CUCtx cuCtx(0);
     int32_t *out = coeff_out;
     for (int i = 0; i < n; i++) {
       const int w = wh[2 * i], h = wh[2 * i + 1];
       std::vector<int32_t> zeros((size_t)w * h, 0);
       std::vector<TCoeff> buf;
       TransformUnit tu;
-      rig.make_tu(tu, buf, w, h, comp[i], rig_flags, zeros.data());
+      rig.make_tu(tu, buf, w, h, comp[i], block_flags ? block_flags[i] : rig_flags, zeros.data());
+      CUCtx cuCtx(0);
       r.residual_coding(tu, ComponentID(comp[i]), cuCtx);
       for (size_t k = 0; k < buf.size(); k++) out[k] = (int32_t)buf[k];
       out += (size_t)w * h;
+      if (info) {
+        info[5 * i + 0] = tu.mtsIdx[comp[i]] == MTS_SKIP;
+        info[5 * i + 1] = int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_LUMA]) | int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_CHROMA]) << 1;
+        info[5 * i + 2] = cuCtx.lfnstLastScanPos;
+        info[5 * i + 3] = cuCtx.violatesMtsCoeffConstraint;
+        info[5 * i + 4] = cuCtx.mtsLastScanPos;
+      }
     }
     if (finish) {
       if (dec.decodeBinTrm() != 1) { strcpy(g_err, "terminate bin is not 1"); return -5; }

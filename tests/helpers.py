@@ -43,6 +43,7 @@ TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_heigh
                      ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
 TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM = 1, 2, 4, 8, 16
 TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
+TU_INFO_TS = 0x20000
 
 
 def TU_MAX_RECORDS(n):
@@ -243,42 +244,54 @@ class CodecLib:
         assert 0 <= n <= cap, n
         return out[:n].copy(), info
 
-    def residual_decode(self, data, qp, blocks_meta, finish=True):
-        """blocks_meta: [(w, h, chroma, flags)] -> (rc, [coefficient blocks (h, w)], n_bits_read)."""
+    def residual_decode(self, data, qp, blocks_meta, finish=True, with_info=False):
+        """blocks_meta: [(w, h, chroma, flags)] -> (rc, [coefficient blocks (h, w)], n_bits_read[, info]).
+        info: per block CABAC_TU_INFO_* as the device parser reports it (scanPosLast | MTS violation, or TS); for the
+        compiled reference it is put together from the TransformUnit / CUCtx the reader leaves behind."""
         data = np.ascontiguousarray(data, np.uint8)
         i32p = ctypes.POINTER(ctypes.c_int32)
         total = sum(w * h for w, h, _, _ in blocks_meta)
         out = np.full(max(total, 1), 0x5A5A5A5A, np.int32)
         nbits = ctypes.c_uint32(0)
+        n = len(blocks_meta)
         if self.p == "orc_":
-            tus = np.zeros(len(blocks_meta), TU_DTYPE)
+            tus = np.zeros(n, TU_DTYPE)
             off = 0
             for i, (w, h, ch, fl) in enumerate(blocks_meta):
                 tus[i]["coeff_offset"], tus[i]["log2_width"], tus[i]["log2_height"] = off, int(np.log2(w)), int(np.log2(h))
                 tus[i]["channel"], tus[i]["flags"] = ch, fl
                 off += w * h
+            info = np.zeros(max(n, 1), np.uint32)
             f = self.lib.orc_residual_decode
             f.restype = ctypes.c_int
-            f.argtypes = [u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, i32p, u32p]
+            f.argtypes = [u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, i32p, u32p,
+                          u32p]
             rc = f(_ptr(data, u8p), len(data), qp, 2, tus.ctypes.data, len(tus), 1 if finish else 0, _ptr(out, i32p),
-                   ctypes.byref(nbits))
+                   ctypes.byref(nbits), _ptr(info, u32p))
+            info = info[:n]
         else:
-            flagsets = {fl & 3 for _, _, _, fl in blocks_meta}
-            assert len(flagsets) <= 1, "the rig has one slice: dep_quant / sign hiding must be the same for all blocks"
-            rig = (flagsets.pop() if flagsets else 0)
-            assert not any(fl & ~3 for _, _, _, fl in blocks_meta)
+            # rig flags (oracle/ref_rig.hpp): bit0 dep_quant, bit1 sign hiding, bit2 transform skip enabled (flag coded),
+            # bit4 the block is transform-skip coded, bit5 BDPCM
+            rig = np.array([(fl & 3) | (4 if fl & TU_TS_FLAG else 0) | (0x10 if fl & TU_TRANSFORM_SKIP else 0) |
+                            (0x20 if fl & TU_BDPCM else 0) for _, _, _, fl in blocks_meta], np.int32)
+            assert not any((fl & TU_TS_FLAG) and (fl & TU_BDPCM) for _, _, _, fl in blocks_meta), \
+                "with BDPCM the reference does not code transform_skip_flag"
             wh = np.array([[w, h] for w, h, _, _ in blocks_meta], np.int32).ravel()
             comp = np.array([1 if ch else 0 for _, _, ch, _ in blocks_meta], np.int32)
+            rinfo = np.zeros(5 * max(n, 1), np.int32)
             ip = ctypes.POINTER(ctypes.c_int)
             f = self.lib.ref_residual_decode
             f.restype = ctypes.c_long
-            f.argtypes = [ctypes.c_int, ip, ip, ctypes.c_int, u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, i32p, u32p]
-            rc = f(len(blocks_meta), wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), rig, _ptr(data, u8p), len(data), qp,
-                   1 if finish else 0, _ptr(out, i32p), ctypes.byref(nbits))
+            f.argtypes = [ctypes.c_int, ip, ip, ctypes.c_int, u8p, ctypes.c_long, ctypes.c_int, ctypes.c_int, i32p, u32p, ip, i32p]
+            rc = f(n, wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), 0, _ptr(data, u8p), len(data), qp,
+                   1 if finish else 0, _ptr(out, i32p), ctypes.byref(nbits), rig.ctypes.data_as(ip), _ptr(rinfo, i32p))
+            info = rinfo.reshape(-1, 5)[:n]
         blocks, off = [], 0
         for w, h, _, _ in blocks_meta:
             blocks.append(out[off:off + w * h].reshape(h, w).copy())
             off += w * h
+        if with_info:
+            return int(rc), blocks, nbits.value, info
         return int(rc), blocks, nbits.value
 
     def scan_order(self, w, h):

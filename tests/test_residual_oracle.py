@@ -193,6 +193,78 @@ def test_residual_parser_with_sign_hiding_matches_reference_reader():
             assert np.array_equal(np.abs(got_o[k]), np.abs(c)), k   # magnitudes always come back
 
 
+def _expected_info(rinfo, w, h, chroma, info):
+    """What the reference reader left in TransformUnit / CUCtx (ref_residual_decode's info) against the parser's info word."""
+    ts, lfnst_viol, lfnst_last, mts_viol, mts_last = (int(x) for x in rinfo)
+    assert bool(info & H.TU_INFO_TS) == bool(ts)
+    if ts:
+        return
+    last = int(info) & 0xFFFF
+    big = w >= 4 and h >= 4
+    max_lfnst = 7 if (w, h) in ((4, 4), (8, 8)) else 15
+    assert lfnst_viol == (int(big and last > max_lfnst) << (1 if chroma else 0))
+    assert lfnst_last == int(big and last >= 1)
+    assert mts_last == int((not chroma) and last >= 1)
+    assert mts_viol == int(bool(info & H.TU_INFO_MTS_VIOLATION))
+
+
+@needs_ref
+def test_transform_skip_parser_matches_reference_reader():
+    """residual_codingTS / residual_coding_subblockTS (cabac_reader.cpp:3130-3339) and ts_flag (:2737-2752): substreams
+    that mix regular blocks, transform-skip blocks whose flag is in the stream, transform-skip blocks without a coded flag
+    and BDPCM blocks, contexts and the arithmetic decoder carrying over; every block comes back exactly (no sign hiding),
+    and the parser reports what the reader leaves in mtsIdx / CUCtx."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0x7500)
+    sizes = [1, 2, 4, 8, 16, 32]
+    for trial in range(12):
+        blocks, metas = [], []
+        for k in range(16):
+            kind = int(rng.integers(0, 5))
+            slice_fl = int(rng.integers(0, 2))                    # dependent quantisation on / off (per block in the rig)
+            if kind == 0:                                         # regular, flag not coded
+                w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 32), (8, 4), (2, 8)][int(rng.integers(0, 7))]
+                c, fl = H.random_block(rng, w, h, density=0.5, big=0.1), slice_fl
+            elif kind == 1:                                       # regular, transform_skip_flag = 0 in the stream
+                w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (16, 4)][int(rng.integers(0, 5))]
+                c, fl = H.random_block(rng, w, h, density=0.5, big=0.1), slice_fl | H.TU_TS_FLAG
+            else:
+                w, h = sizes[int(rng.integers(0, 6))], sizes[int(rng.integers(0, 6))]
+                if w * h == 1:
+                    w = 2
+                c = _ts_block(rng, w, h, int(rng.integers(0, 4)))
+                fl = slice_fl | H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, 0, H.TU_BDPCM][kind - 2]
+            blocks.append(c)
+            metas.append((w, h, int(rng.integers(0, 2)), fl))
+        qp = int(rng.integers(20, 45))
+        data, _ = _encode_blocks(orc, blocks, [m[2] for m in metas], [m[3] for m in metas], qp=qp)
+        rc_o, got_o, nb_o, info_o = orc.residual_decode(data, qp, metas, with_info=True)
+        assert rc_o == 0, trial
+        rc_r, got_r, nb_r, info_r = ref.residual_decode(data, qp, metas, with_info=True)
+        assert rc_r == 0 and nb_r == nb_o, trial
+        for k, c in enumerate(blocks):
+            assert np.array_equal(got_r[k], c) and np.array_equal(got_o[k], c), (trial, k, metas[k])
+            _expected_info(info_r[k], metas[k][0], metas[k][1], metas[k][2], int(info_o[k]))
+
+
+@needs_ref
+def test_transform_skip_parser_budget_and_escapes():
+    """Blocks that exhaust the 7/4 bins-per-sample budget (bypass-coded levels with bypass signs) and 32-bin escapes."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    for w, h in [(4, 4), (32, 32), (8, 16), (2, 2), (1, 16)]:
+        for v in (1, -7, 2000, -32768):
+            c = np.full((h, w), v, np.int32)
+            c[::2, 1::2] = -v if v != -32768 else 32767
+            for fl in (H.TU_TRANSFORM_SKIP | H.TU_TS_FLAG, H.TU_TRANSFORM_SKIP | H.TU_BDPCM, H.TU_TRANSFORM_SKIP):
+                metas = [(w, h, 0, fl), (w, h, 1, fl)]
+                data, _ = _encode_blocks(orc, [c, c], [0, 1], [fl, fl])
+                rc_r, got_r, nb_r = ref.residual_decode(data, 32, metas)
+                rc_o, got_o, nb_o = orc.residual_decode(data, 32, metas)
+                assert rc_r == 0 and rc_o == 0 and nb_r == nb_o, (w, h, v, fl)
+                for k in range(2):
+                    assert np.array_equal(got_r[k], c) and np.array_equal(got_o[k], c), (w, h, v, fl, k)
+
+
 def test_residual_parser_errors():
     orc = H.load_oracle()
     c = np.array([[3, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 2]], np.int32)
@@ -200,7 +272,7 @@ def test_residual_parser_errors():
     rc, got, _ = orc.residual_decode(data, 32, [(4, 4, 0, 0)])
     assert rc == 0 and np.array_equal(got[0], c)
     assert orc.residual_decode(data[:1], 32, [(4, 4, 0, 0)])[0] == -4                 # read past the end
-    assert orc.residual_decode(data, 32, [(4, 4, 0, H.TU_TRANSFORM_SKIP)])[0] == -2   # not covered by the parser
+    assert orc.residual_decode(data, 32, [(64, 64, 0, H.TU_TRANSFORM_SKIP)])[0] == -2  # transform skip stops at 32 x 32
 
 
 def test_golden_parse_substreams():
@@ -210,6 +282,8 @@ def test_golden_parse_substreams():
     for s in range(int(g["n_sub"][0])):
         metas = [tuple(int(x) for x in m) for m in g["s%d_meta" % s]]
         qp, nbits = [int(x) for x in g["s%d_qp" % s]]
-        rc, dec, nb = orc.residual_decode(g["s%d_bytes" % s], qp, metas)
+        rc, dec, nb, info = orc.residual_decode(g["s%d_bytes" % s], qp, metas, with_info=True)
         assert rc == 0 and nb == nbits
         assert np.array_equal(np.concatenate([d.ravel() for d in dec]), g["s%d_coeff" % s]), s
+        for k, m in enumerate(metas):      # mtsIdx / CUCtx as the reference reader left them
+            _expected_info(g["s%d_refinfo" % s][k], m[0], m[1], m[2], int(info[k]))
