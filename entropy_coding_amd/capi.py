@@ -72,8 +72,8 @@ def load_library():
     L.cabac_hip_ctx_init_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_binarize_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
-    L.cabac_hip_residual_parse_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
-    L.cabac_hip_residual_parse_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp]
+    L.cabac_hip_residual_parse_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    L.cabac_hip_residual_parse_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
@@ -265,23 +265,26 @@ class CabacHip:
         self._check(self.L.cabac_hip_residual_device(self.h, n_tu, vp(d_tu), vp(d_coeff), vp(d_rec_offset),
                                                      vp(d_n_records), vp(d_info), vp(d_records)))
 
-    def residual_parse_device(self, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results):
+    def residual_parse_device(self, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results, d_tu_info=0):
         """cabac_hip_residual_parse_device: bytes -> coefficient blocks, contexts derived on the device."""
         self._check(self.L.cabac_hip_residual_parse_device(self.h, n_sub, vp(d_desc), vp(d_bytes), vp(d_tile_first), vp(d_tu),
-                                                           vp(d_coeff), vp(d_results)))
+                                                           vp(d_coeff), vp(d_tu_info) if d_tu_info else None, vp(d_results)))
 
-    def residual_parse_batch(self, desc, data, tile_first, tus, n_coeff_total, check=True):
-        """Host arrays in, (coeff, results) out (cabac_hip_residual_parse_batch, synchronous)."""
+    def residual_parse_batch(self, desc, data, tile_first, tus, n_coeff_total, check=True, with_info=False):
+        """Host arrays in, (coeff, results[, info]) out (cabac_hip_residual_parse_batch, synchronous)."""
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         data = np.ascontiguousarray(data, np.uint8)
         tile_first = np.ascontiguousarray(tile_first, np.uint32)
         tus = np.ascontiguousarray(tus, TU_DTYPE)
         coeff = np.zeros(max(int(n_coeff_total), 1), np.int32)
         res = np.zeros(max(len(desc), 1), RESULT_DTYPE)
+        info = np.zeros(max(len(tus), 1), np.uint32)
         rc = self.L.cabac_hip_residual_parse_batch(self.h, len(desc), desc.ctypes.data, data.ctypes.data, len(data),
                                                    tile_first.ctypes.data, tus.ctypes.data, coeff.ctypes.data, int(n_coeff_total),
-                                                   res.ctypes.data)
+                                                   info.ctypes.data, res.ctypes.data)
         self._check(rc, allow_substream=not check)
+        if with_info:
+            return coeff[: int(n_coeff_total)], res[: len(desc)], info[: len(tus)]
         return coeff[: int(n_coeff_total)], res[: len(desc)]
 
     def residual_batch(self, tus, coeff, check=True):

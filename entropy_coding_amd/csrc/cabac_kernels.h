@@ -43,8 +43,9 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
                            void *scratch);
 
 // residual parser (cabac_residual.hip): bytes -> coefficient blocks, one substream = blocks [tile_first[s], tile_first[s+1])
+// (cabac_residual_parse.hip); tu_info (may be null): per block scanPosLast | CABAC_TU_INFO_*
 hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
-                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
+                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff, uint32_t *tu_info,
                                  cabac_substream_result *results);
 
 // substream assembly (cabac_assemble.hip)

@@ -722,370 +722,7 @@ __global__ __launch_bounds__(256) void residual_ts_kernel(uint32_t n_tu, uint32_
     residual_rows<kWrite, 0u, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
 }
 
-// ---- residual parser (decoder side) ----------------------------------------------------------
-// CABACReader::residual_coding (cabac_reader.cpp:2647-2735), last_sig_coeff (:2865-2938), residual_coding_subblock
-// (:2946-3128) on top of the bin decoder (TBinDecoder::decodeBin, decodeBinEP, decodeBinsEP, decodeRemAbsEP,
-// decodeBinTrm, finish: arith_codec.cpp:60-277): bytes -> coefficient blocks, the context of every bin derived from
-// the coefficients decoded so far — nothing but the block geometry is supplied.  This is a serial walk by its nature
-// (each context choice waits for the previous bins); first version: one wave per substream, lane 0 parses with the
-// context store and the current block in LDS, all lanes write the finished block out.  Regular residual coding only.
-namespace {
-
-struct ParseDec {  // BinDecoderBase state
-  uint32_t range, value;
-  int32_t bits_needed;
-  const uint8_t *src;
-  uint32_t pos, cap, underrun;
-  // the input is consumed 16 bytes at a time: the current chunk and the next one (loaded a chunk ahead, so that the
-  // serial walk never waits for memory) live in registers
-  uint64_t cur_lo, cur_hi, nxt_lo, nxt_hi;
-  uint32_t chunk;  // byte position of the current chunk
-};
-
-// bytes [at, at + 16) of the substream; beyond byte_capacity reads as zero, never touching memory there
-__device__ __forceinline__ void pd_load16(const ParseDec &d, uint32_t at, uint64_t &lo, uint64_t &hi) {
-  if (at + 16u <= d.cap && (reinterpret_cast<uintptr_t>(d.src) & 15u) == 0u) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(d.src + at);
-    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-  } else {
-    lo = hi = 0;
-#pragma unroll 1
-    for (uint32_t i = 0; i < 16u; i++) {  // the tail of the substream (or an unaligned buffer): rare, keep it small
-      const uint64_t b = at + i < d.cap ? d.src[at + i] : 0u;
-      if (i < 8u) lo |= b << (8u * i);
-      else hi |= b << (8u * (i - 8u));
-    }
-  }
-}
-
-__device__ __forceinline__ void pd_open(ParseDec &d) {
-  d.chunk = 0;
-  pd_load16(d, 0u, d.cur_lo, d.cur_hi);
-  pd_load16(d, 16u, d.nxt_lo, d.nxt_hi);
-}
-
-__device__ __forceinline__ uint32_t pd_byte(ParseDec &d) {  // InputBitstream::readByte, bit_stream.cpp:268-274
-  if (d.pos >= d.chunk + 16u) {
-    d.cur_lo = d.nxt_lo;
-    d.cur_hi = d.nxt_hi;
-    d.chunk += 16u;
-    pd_load16(d, d.chunk + 16u, d.nxt_lo, d.nxt_hi);
-  }
-  const uint32_t i = d.pos - d.chunk;
-  const uint32_t b = (uint32_t)((i < 8u ? d.cur_lo >> (8u * i) : d.cur_hi >> (8u * (i - 8u))) & 0xffu);
-  if (d.pos >= d.cap) d.underrun = 1;
-  d.pos++;
-  return b;
-}
-
-__device__ __forceinline__ uint32_t pd_bin(ParseDec &d, CtxEntry *ctx, uint32_t id) {  // arith_codec.cpp:242-277
-  const CtxEntry e = ctx[id];
-  const uint32_t q8 = state8(e.state);
-  uint32_t bin = q8 >> 7;
-  const uint32_t lps = lps_of(q8, d.range);
-  d.range -= lps;
-  const uint32_t sr = d.range << 7;
-  if (d.value < sr) {
-    if (d.range < 256u) {
-      d.range <<= 1;
-      d.value <<= 1;
-      if (++d.bits_needed == 0) {
-        d.bits_needed = -8;
-        d.value += pd_byte(d);
-      }
-    }
-  } else {
-    bin = 1u - bin;
-    const int nb = renorm_bits_lps(lps);
-    d.value = (d.value - sr) << nb;
-    d.range = lps << nb;
-    d.bits_needed += nb;
-    if (d.bits_needed >= 0) {
-      d.value += pd_byte(d) << d.bits_needed;
-      d.bits_needed -= 8;
-    }
-  }
-  ctx[id].state = ctx_update(e.state, e.rates, bin);
-  return bin;
-}
-
-__device__ __forceinline__ uint32_t pd_ep(ParseDec &d) {  // decodeBinEP, arith_codec.cpp:100-114
-  d.value += d.value;
-  if (++d.bits_needed >= 0) {
-    d.bits_needed = -8;
-    d.value += pd_byte(d);
-  }
-  const uint32_t sr = d.range << 7;
-  if (d.value >= sr) {
-    d.value -= sr;
-    return 1u;
-  }
-  return 0u;
-}
-
-__device__ __forceinline__ uint32_t pd_bins_ep(ParseDec &d, uint32_t n) {  // decodeBinsEP is n single bypass bins, MSB first
-  uint32_t v = 0;
-  for (uint32_t i = 0; i < n; i++) v = (v << 1) | pd_ep(d);
-  return v;
-}
-
-__device__ __forceinline__ uint32_t pd_rem_abs(ParseDec &d, uint32_t rice, uint32_t max_log2) {  // decodeRemAbsEP, :153-179
-  const uint32_t cutoff = 5u, max_prefix = 32u - cutoff - max_log2;
-  uint32_t prefix = 0;
-  while (prefix < cutoff + max_prefix && pd_ep(d)) prefix++;
-  if (prefix < cutoff) return (prefix << rice) + pd_bins_ep(d, rice);
-  const uint32_t ext = prefix - cutoff;
-  const uint32_t length = ext == max_prefix ? max_log2 : ext + rice;
-  const uint32_t offset = (((1u << ext) - 1u) + cutoff) << rice;
-  return offset + pd_bins_ep(d, length);
-}
-
-}  // namespace
-
-__global__ __launch_bounds__(64) void residual_parse_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
-                                                             const uint8_t *__restrict__ bytes,
-                                                             const uint32_t *__restrict__ tile_first,
-                                                             const cabac_tu_desc *__restrict__ tus, int32_t *__restrict__ coeff_all,
-                                                             cabac_substream_result *__restrict__ results) {
-  __shared__ CtxEntry ctx[kNumCtx + 5];
-  __shared__ int32_t blk[1024];  // the coded region of the current block, pitch = its width (at most 32)
-  const uint32_t lane = threadIdx.x, sub = blockIdx.x;
-  if (sub >= n_sub) return;
-  const cabac_substream_desc d = desc[sub];
-  ctx_store_init(ctx, d.qp, d.init_id & 3u, (int)lane);
-  for (uint32_t i = lane; i < 1024u; i += 64u) blk[i] = 0;
-  __syncthreads();
-
-  ParseDec dec;
-  dec.src = bytes + d.byte_offset;
-  dec.cap = d.byte_capacity;
-  dec.pos = 0;
-  dec.underrun = 0;
-  dec.range = 510u;  // BinDecoderBase::start, arith_codec.cpp:60-66
-  dec.value = 0;
-  dec.bits_needed = -8;
-  dec.cur_lo = dec.cur_hi = dec.nxt_lo = dec.nxt_hi = 0;
-  dec.chunk = 0;
-  if (lane == 0u) {
-    pd_open(dec);
-    dec.value = pd_byte(dec) << 8;
-    dec.value += pd_byte(dec);
-  }
-  uint32_t flags_out = 0;
-
-  for (uint32_t t = tile_first[sub]; t < tile_first[sub + 1]; t++) {
-    const cabac_tu_desc tu = tus[t];
-    const uint32_t lw = tu.log2_width, lh = tu.log2_height, chroma = tu.channel, fl = tu.flags;
-    const uint32_t max_log2 = tu.max_log2_tr_range ? tu.max_log2_tr_range : 15u;
-    if (lw > 6u || lh > 6u || chroma > 1u || max_log2 > 20u || (fl & CABAC_TU_TRANSFORM_SKIP)) {
-      flags_out |= CABAC_RES_BAD_RECORD;  // a block this parser does not cover: stop here
-      break;
-    }
-    const uint32_t w = 1u << lw, h = 1u << lh, we = w < 32u ? w : 32u, he = h < 32u ? h : 32u;
-    const uint32_t lwe = 31u - (uint32_t)__builtin_clz(we);
-    if (lane == 0u) {
-      uint32_t cgw_l2, cgh_l2;  // g_log2SbbSize, rom.cpp:41-50
-      if (lw == 0u) { cgw_l2 = 0u; cgh_l2 = lh < 4u ? lh : 4u; }
-      else if (lh == 0u) { cgw_l2 = lw < 4u ? lw : 4u; cgh_l2 = 0u; }
-      else if (lw == 1u) { cgw_l2 = 1u; cgh_l2 = lh <= 2u ? 1u : 3u; }
-      else if (lh == 1u) { cgh_l2 = 1u; cgw_l2 = lw <= 2u ? 1u : 3u; }
-      else { cgw_l2 = 2u; cgh_l2 = 2u; }
-      const uint32_t cg_l2 = cgw_l2 + cgh_l2, cg_size = 1u << cg_l2;
-      const uint32_t lwg = lwe - cgw_l2, lhg = (31u - (uint32_t)__builtin_clz(he)) - cgh_l2, wg = 1u << lwg, hg = 1u << lhg;
-      const uint8_t *grid = c_diag.grid[lwg][lhg];
-      const uint8_t *in_cg = c_diag.in_cg[cgw_l2][cgh_l2];
-      auto pos_xy = [&](uint32_t p, uint32_t &x, uint32_t &y) {
-        const uint32_t gp = grid[p >> cg_l2], ip = in_cg[p & (cg_size - 1u)];
-        x = ((gp & 15u) << cgw_l2) + (ip & 15u);
-        y = ((gp >> 4) << cgh_l2) + (ip >> 4);
-      };
-      // five-sample template of the levels decoded so far (context_modelling.hpp:71-117, :152-176)
-      auto tmpl = [&](uint32_t x, uint32_t y, int &sum_abs, int &sum_clip, int &n_nz) {
-        sum_abs = sum_clip = n_nz = 0;
-        auto add = [&](uint32_t xx, uint32_t yy) {
-          if (xx < we && yy < he) {
-            int a = blk[(yy << lwe) + xx];
-            a = a < 0 ? -a : a;
-            sum_abs += a;
-            sum_clip += min(a, 4 + (a & 1));
-            n_nz += a != 0;
-          }
-        };
-        add(x + 1u, y); add(x + 2u, y); add(x + 1u, y + 1u); add(x, y + 1u); add(x, y + 2u);
-      };
-
-      if (fl & CABAC_TU_TS_FLAG) (void)pd_bin(dec, ctx, CABAC_CTX_TRANSFORM_SKIP_FLAG(chroma));
-      // last significant position
-      const uint32_t luma_off_x = lw < 3u ? 0u : lw == 3u ? 3u : lw == 4u ? 6u : lw == 5u ? 10u : 15u;
-      const uint32_t luma_off_y = lh < 3u ? 0u : lh == 3u ? 3u : lh == 4u ? 6u : lh == 5u ? 10u : 15u;
-      const uint32_t off_x = chroma ? 0u : luma_off_x, off_y = chroma ? 0u : luma_off_y;
-      const uint32_t sh_x = chroma ? min(w >> 3, 2u) : (lw + 1u) >> 2, sh_y = chroma ? min(h >> 3, 2u) : (lh + 1u) >> 2;
-      const uint32_t max_x = group_idx(we - 1u), max_y = group_idx(he - 1u);
-      uint32_t px = 0, py = 0;
-      while (px < max_x && pd_bin(dec, ctx, CABAC_CTX_LAST_X(chroma) + off_x + (px >> sh_x))) px++;
-      while (py < max_y && pd_bin(dec, ctx, CABAC_CTX_LAST_Y(chroma) + off_y + (py >> sh_y))) py++;
-      if (px > 3u) px = min_in_group(px) + pd_bins_ep(dec, (px - 2u) >> 1);
-      if (py > 3u) py = min_in_group(py) + pd_bins_ep(dec, (py - 2u) >> 1);
-      px = min(px, we - 1u);  // a corrupt stream must not lead outside the block
-      py = min(py, he - 1u);
-      uint32_t last = 0;
-      {
-        const uint32_t want_g = (px >> cgw_l2) | ((py >> cgh_l2) << 4), want_i = (px & ((1u << cgw_l2) - 1u)) | ((py & ((1u << cgh_l2) - 1u)) << 4);
-        uint32_t cgi = 0, ii = 0;
-        while (cgi + 1u < wg * hg && grid[cgi] != want_g) cgi++;
-        while (ii + 1u < cg_size && in_cg[ii] != want_i) ii++;
-        last = (cgi << cg_l2) + ii;
-      }
-
-      const uint32_t trans = (fl & CABAC_TU_DEP_QUANT) ? 32040u : 0u;
-      uint32_t state = 0;
-      int budget = (int)((we * he * 28u) >> 4);
-      uint64_t sig_map = 0;
-      const int last_cg = (int)(last >> cg_l2);
-      for (int cg = last_cg; cg >= 0; cg--) {
-        const uint32_t lo = (uint32_t)cg << cg_l2;
-        const uint32_t gp = grid[cg], gx = gp & 15u, gy = gp >> 4, gbit = gy * wg + gx;
-        bool sig = cg == last_cg || cg == 0;
-        if (!sig) {
-          const uint32_t right = gx + 1u < wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
-          const uint32_t below = gy + 1u < hg ? (uint32_t)(sig_map >> (gbit + wg)) & 1u : 0u;
-          sig = pd_bin(dec, ctx, CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)) != 0u;
-        }
-        if (!sig) continue;
-        sig_map |= 1ull << gbit;
-        const int first = cg == last_cg ? (int)last : (int)(lo + cg_size - 1u);
-        const int infer = cg == last_cg ? (int)last : (cg != 0 ? (int)lo : -1);
-        int n_nz = 0, first_nz = first, last_nz = -1, p;
-        uint16_t nz_pos[16];
-        for (p = first; p >= (int)lo && budget >= 4; p--) {  // pass 1
-          uint32_t x, y;
-          pos_xy((uint32_t)p, x, y);
-          const uint32_t diag = x + y;
-          int sum_abs, sum_clip, n_t;
-          tmpl(x, y, sum_abs, sum_clip, n_t);
-          uint32_t sf = (!n_nz && p == infer) ? 1u : 0u;
-          if (!sf) {
-            uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + (diag < 2u ? 4u : 0u);
-            if (chroma == 0u) ofs += diag < 5u ? 4u : 0u;
-            sf = pd_bin(dec, ctx, CABAC_CTX_SIG_FLAG(chroma + 2u * (state > 1u ? state - 1u : 0u)) + ofs);
-            budget--;
-          }
-          int level = 0;
-          if (sf) {
-            uint32_t aofs = 0;
-            if (p != (int)last) {
-              aofs = (uint32_t)min(sum_clip - n_t, 4) + 1u;
-              if (diag == 0u) aofs += chroma ? 5u : 15u;
-              else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
-            }
-            nz_pos[n_nz++] = (uint16_t)p;
-            first_nz = p;
-            last_nz = max(last_nz, p);
-            const uint32_t g1 = pd_bin(dec, ctx, CABAC_CTX_GTX_FLAG(2u + chroma) + aofs);
-            uint32_t par = 0, g2 = 0;
-            budget--;
-            if (g1) {
-              par = pd_bin(dec, ctx, CABAC_CTX_PAR_FLAG(chroma) + aofs);
-              g2 = pd_bin(dec, ctx, CABAC_CTX_GTX_FLAG(chroma) + aofs);
-              budget -= 2;
-            }
-            level = (int)(1u + par + g1 + (g2 << 1));
-            blk[(y << lwe) + x] = level;
-          }
-          state = (trans >> ((state << 2) + (((uint32_t)level & 1u) << 1))) & 3u;
-        }
-        const int bypass_from = p;
-        for (int q = first; q > bypass_from; q--) {  // pass 2: remainders of the context-coded levels
-          uint32_t x, y;
-          pos_xy((uint32_t)q, x, y);
-          const int v = blk[(y << lwe) + x];
-          if (v >= 4) {
-            int sum_abs, sum_clip, n_t;
-            tmpl(x, y, sum_abs, sum_clip, n_t);
-            blk[(y << lwe) + x] = v + (int)(pd_rem_abs(dec, rice_of(sum_abs, 4), max_log2) << 1);
-          }
-        }
-        for (int q = bypass_from; q >= (int)lo; q--) {  // pass 3: whole levels in bypass mode
-          uint32_t x, y;
-          pos_xy((uint32_t)q, x, y);
-          int sum_abs, sum_clip, n_t;
-          tmpl(x, y, sum_abs, sum_clip, n_t);
-          const uint32_t rice = rice_of(sum_abs, 0);
-          const uint32_t pos0 = (state < 2u ? 1u : 2u) << rice;
-          const uint32_t rem = pd_rem_abs(dec, rice, max_log2);
-          const uint32_t v = rem == pos0 ? 0u : (rem < pos0 ? rem + 1u : rem);
-          state = (trans >> ((state << 2) + ((v & 1u) << 1))) & 3u;
-          if (v) {
-            nz_pos[n_nz++] = (uint16_t)q;
-            first_nz = q;
-            last_nz = max(last_nz, q);
-            blk[(y << lwe) + x] = (int)v;
-          }
-        }
-        // signs; with sign-data hiding the last one follows from the parity of the level sum (:3100-3126)
-        const bool hide = (fl & CABAC_TU_SIGN_HIDING) && last_nz - first_nz >= 4;
-        const int n_signs = hide ? n_nz - 1 : n_nz;
-        const uint32_t pattern = pd_bins_ep(dec, (uint32_t)n_signs);
-        int sum = 0;
-        for (int k = 0; k < n_nz; k++) {
-          uint32_t x, y;
-          pos_xy(nz_pos[k], x, y);
-          const int a = blk[(y << lwe) + x];
-          sum += a;
-          const bool neg = k < n_signs ? ((pattern >> (n_signs - 1 - k)) & 1u) != 0u : (sum & 1) != 0;
-          if (neg) blk[(y << lwe) + x] = -a;
-        }
-        if (dec.underrun) break;  // nothing sensible follows
-      }
-    }
-    // every lane: the finished block goes out row by row, the LDS copy is cleared for the next block
-    int32_t *out = coeff_all + tu.coeff_offset;
-    for (uint32_t i = lane; i < we * he; i += 64u) {
-      out[((i >> lwe) << lw) + (i & (we - 1u))] = blk[i];
-      blk[i] = 0;
-    }
-    if (__shfl((int)dec.underrun, 0)) break;
-  }
-
-  if (lane == 0u) {
-    if ((d.init_id & CABAC_SUB_FINISH) && !flags_out && !dec.underrun) {
-      // encodeBinTrm(1) closes the substream (cabac_writer.cpp:104-107); decodeBinTrm, arith_codec.cpp:181-197
-      dec.range -= 2u;
-      const uint32_t sr = dec.range << 7;
-      uint32_t trm = 0;
-      if (dec.value >= sr) trm = 1;
-      else if (dec.range < 256u) {
-        dec.range <<= 1;
-        dec.value <<= 1;
-        if (++dec.bits_needed == 0) {
-          dec.bits_needed = -8;
-          dec.value += pd_byte(dec);
-        }
-      }
-      // finish(), arith_codec.cpp:68-73: the last byte read holds the stop bit where the decoder stands
-      bool stop_ok = false;
-      if (trm && dec.pos >= 1u && dec.pos <= dec.cap) {
-        const uint32_t lastb = dec.src[dec.pos - 1u];
-        stop_ok = ((lastb << (8 + dec.bits_needed)) & 0xffu) == 0x80u;
-      }
-      if (!dec.underrun && !(trm && stop_ok)) flags_out |= CABAC_RES_BAD_STOP;
-    }
-    if (dec.underrun) flags_out |= CABAC_RES_UNDERRUN;
-    cabac_substream_result r;
-    r.n_bits = 8u * dec.pos + (uint32_t)dec.bits_needed;
-    r.flags = flags_out;
-    results[sub] = r;
-  }
-}
-
-hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
-                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
-                                 cabac_substream_result *results) {
-  if (n_sub == 0) return hipSuccess;
-  hipLaunchKernelGGL(residual_parse_kernel, dim3(n_sub), dim3(64), 0, st, n_sub, desc, bytes, tile_first, tus, coeff, results);
-  return hipGetLastError();
-}
+// (the residual parser lives in cabac_residual_parse.hip)
 
 size_t residual_scratch_bytes(uint32_t n_tu) {
   return sizeof(uint32_t) * (kScratchHeader + (size_t)n_tu + kClasses * kRowsPerBlock);

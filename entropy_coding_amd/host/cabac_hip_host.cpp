@@ -296,7 +296,7 @@ HipBatch::ResidualResult HipBatch::residual(const std::vector<ResidualBlock> &bl
   return r;
 }
 
-std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<ParseJob> &jobs) {
+std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<ParseJob> &jobs, std::vector<uint32_t> *info_out) {
   const uint32_t n = uint32_t(jobs.size());
   std::vector<std::vector<int32_t>> out(n);
   if (n == 0) return out;
@@ -315,15 +315,16 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
       unsigned lw = 0, lh = 0;
       while ((1u << lw) < b.width) lw++;
       while ((1u << lh) < b.height) lh++;
-      if ((1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6 || b.transformSkip)
-        throw Exception("residualParse: power-of-two blocks up to 64, regular residual coding only");
+      if ((1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6)
+        throw Exception("residualParse: power-of-two blocks up to 64");
       cabac_tu_desc t{};
       t.coeff_offset = coeff_total;
       t.log2_width = uint8_t(lw);
       t.log2_height = uint8_t(lh);
       t.channel = b.chroma ? 1 : 0;
       t.flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
-                        (b.tsFlag ? CABAC_TU_TS_FLAG : 0u));
+                        (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
+                        (b.bdpcm ? CABAC_TU_BDPCM : 0u));
       t.max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
       tus.push_back(t);
       coeff_total += uint64_t(b.width) * b.height;
@@ -336,8 +337,9 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
   std::vector<int32_t> coeff(coeff_total ? coeff_total : 1, 0);
   std::vector<cabac_substream_result> res(n);
   if (tus.empty()) tus.push_back(cabac_tu_desc{});
+  if (info_out) info_out->assign(tus.size(), 0u);
   const int rc = cabac_hip_residual_parse_batch(handle(), n, desc.data(), bytes.data(), bytes.size(), first.data(), tus.data(),
-                                                coeff.data(), coeff_total, res.data());
+                                                coeff.data(), coeff_total, info_out ? info_out->data() : nullptr, res.data());
   if (rc == CABAC_HIP_ERR_SUBSTREAM) {
     for (uint32_t s = 0; s < n; s++) {
       if (res[s].flags & CABAC_RES_UNDERRUN) throw Exception("FIFO exceeded");

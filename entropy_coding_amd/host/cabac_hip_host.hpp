@@ -197,10 +197,13 @@ public:
   };
   ResidualResult residual(const std::vector<ResidualBlock> &blocks);
 
-  // Residual parser (CABACReader::residual_coding, cabac_reader.cpp:2647-3128): the blocks of each substream decoded from
-  // its bytes, every context derived on the device.  blocks[i] gives the geometry (coeff is ignored); the result holds the
-  // blocks of all substreams back to back (width * height each).  Throws Exception like the reference's CHECKs on a
-  // substream that runs out of bytes or misses its terminate bin / stop pattern.
+  // Residual parser (CABACReader::residual_coding, cabac_reader.cpp:2647-3339): the blocks of each substream decoded from
+  // its bytes, every context derived on the device.  blocks[i] gives the geometry (coeff is ignored); tsFlag: the
+  // transform_skip_flag is in the stream and decides between regular and transform-skip residual coding, otherwise
+  // transformSkip does (with bdpcm as given).  The result holds the blocks of all substreams back to back (width * height
+  // each); info (optional) one word per block: scanPosLast | CABAC_TU_INFO_MTS_VIOLATION, or CABAC_TU_INFO_TS for a block
+  // parsed as transform skip.  Throws Exception like the reference's CHECKs on a substream that runs out of bytes or
+  // misses its terminate bin / stop pattern.
   struct ParseJob {
     const uint8_t *bytes;
     uint32_t n_bytes;
@@ -208,7 +211,7 @@ public:
     int initId;
     std::vector<ResidualBlock> blocks;
   };
-  std::vector<std::vector<int32_t>> residualParse(const std::vector<ParseJob> &jobs);
+  std::vector<std::vector<int32_t>> residualParse(const std::vector<ParseJob> &jobs, std::vector<uint32_t> *info = nullptr);
 
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through

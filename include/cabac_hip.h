@@ -322,24 +322,35 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
                              uint64_t *frac_bits, uint32_t *flags);
 
 /* ---- residual parser on the device (decoder side) ------------------------------------
- * CABACReader::residual_coding (cabac_reader.cpp:2647-2735) with last_sig_coeff (:2865-2938) and
- * residual_coding_subblock (:2946-3128) on top of the bin decoder: bytes -> transform-block coefficients.  Unlike
- * cabac_hip_decode_device no bin / context sequence is supplied: every context follows from the coefficients decoded
- * so far; only the geometry of the blocks is given.  Substream s (desc[s]: byte_offset, byte_capacity, qp, init_id |
- * CABAC_SUB_FINISH) holds the blocks d_tile_first[s] .. d_tile_first[s+1]-1 of d_tu in order, then — with
- * CABAC_SUB_FINISH — the terminate bin 1 and the stop pattern, which are checked.  Block t is written to
- * d_coeff + d_tu[t].coeff_offset (int32, raster, stride = width; of a 64-wide/tall block only the coded top-left
- * 32 x 32).  results[s] = {bits read, CABAC_RES_UNDERRUN | CABAC_RES_BAD_STOP | CABAC_RES_BAD_RECORD (a block the
- * parser does not cover: transform skip, bad size)}.  Regular residual coding; flags as for the binariser.        */
+ * CABACReader::residual_coding (cabac_reader.cpp:2647-2735) with ts_flag (:2737-2752), last_sig_coeff (:2865-2938),
+ * residual_coding_subblock (:2946-3128), residual_codingTS and residual_coding_subblockTS (:3130-3339) on top of the bin
+ * decoder: bytes -> transform-block coefficients.  Unlike cabac_hip_decode_device no bin / context sequence is supplied:
+ * every context follows from the coefficients decoded so far; only the geometry of the blocks is given.  Substream s
+ * (desc[s]: byte_offset, byte_capacity, qp, init_id | CABAC_SUB_FINISH) holds the blocks d_tile_first[s] ..
+ * d_tile_first[s+1]-1 of d_tu in order, then — with CABAC_SUB_FINISH — the terminate bin 1 and the stop pattern, which
+ * are checked.  Block t is written to d_coeff + d_tu[t].coeff_offset (int32, raster, stride = width; of a 64-wide/tall
+ * block only the coded top-left 32 x 32).
+ * Block flags (cabac_tu_desc.flags): DEP_QUANT, SIGN_HIDING as for the binariser; CABAC_TU_TS_FLAG: transform_skip_flag
+ * is in the stream (TU::isTSAllowed) and the block is parsed as that bin says, whatever CABAC_TU_TRANSFORM_SKIP says;
+ * without it CABAC_TU_TRANSFORM_SKIP decides (the reference infers the flag for BDPCM blocks); CABAC_TU_BDPCM:
+ * cu.bdpcmMode / bdpcmModeChroma.  Transform-skip blocks up to 32 x 32.  SBT/MTS zero-out and the range extensions are
+ * not covered.
+ * d_tu_info[t] (may be NULL): for a regular block scanPosLast | CABAC_TU_INFO_MTS_VIOLATION — what residual_coding
+ * leaves in its CUCtx argument (:2675-2693, :2729-2732) follows from it —, for a block parsed as transform skip
+ * CABAC_TU_INFO_TS (the reader sets mtsIdx = MTS_SKIP).
+ * results[s] = {bits read, CABAC_RES_UNDERRUN | CABAC_RES_BAD_STOP | CABAC_RES_BAD_RECORD (a block the parser does not
+ * cover: bad size, transform skip beyond 32 x 32; parsing of the substream stops there)}.                          */
 int cabac_hip_residual_parse_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
                                     const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
-                                    int32_t *d_coeff, cabac_substream_result *d_results);
+                                    int32_t *d_coeff, uint32_t *d_tu_info, cabac_substream_result *d_results);
 
 /* Host-pointer form of cabac_hip_residual_parse_device (synchronous).  bytes_total / n_coeff_total bound the two
- * buffers; coeff receives the blocks at tus[t].coeff_offset.  Returns CABAC_HIP_ERR_SUBSTREAM if any result flag is set. */
+ * buffers; coeff receives the blocks at tus[t].coeff_offset, tu_info (may be NULL) one word per block.  Returns
+ * CABAC_HIP_ERR_SUBSTREAM if any result flag is set. */
 int cabac_hip_residual_parse_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
                                    uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus,
-                                   int32_t *coeff, uint64_t n_coeff_total, cabac_substream_result *results);
+                                   int32_t *coeff, uint64_t n_coeff_total, uint32_t *tu_info,
+                                   cabac_substream_result *results);
 
 /* Host-pointer form of cabac_hip_residual_device (synchronous, both passes).  `offsets` receives n_tu + 1 record
  * offsets (block t's records are records[offsets[t] .. offsets[t+1])); n_records/info as on the device, info may

@@ -1,4 +1,4 @@
-"""GPU: the residual parser (cabac_hip_residual_parse_device, csrc/cabac_residual.hip) — bytes -> coefficient blocks with
+"""GPU: the residual parser (cabac_hip_residual_parse_device, csrc/cabac_residual_parse.hip) — bytes -> coefficient blocks with
 the contexts derived on the device — through the C ABI against the oracle's parser (orc_residual_decode, pinned to the
 reference's CABACReader::residual_coding by tests/test_residual_oracle.py) and against the coefficients that were coded."""
 import numpy as np
@@ -64,9 +64,12 @@ def parse(hip, subs, qps, capacities=None, finish=True, mutate=None):
     t_tu = torch.from_numpy(tus.view(np.uint8).reshape(-1).copy()).cuda()
     t_co = torch.full((max(off, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
     t_res = torch.full((2 * n_sub,), -1, dtype=torch.int32, device="cuda")
+    t_info = torch.full((max(len(metas), 1),), -1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    hip.residual_parse_device(n_sub, t_desc.data_ptr(), t_buf.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(), t_co.data_ptr(), t_res.data_ptr())
+    hip.residual_parse_device(n_sub, t_desc.data_ptr(), t_buf.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(), t_co.data_ptr(), t_res.data_ptr(),
+                              d_tu_info=t_info.data_ptr())
     hip.synchronize()
+    parse.last_info = t_info.cpu().numpy().view(np.uint32)
     co = t_co.cpu().numpy()
     res = t_res.cpu().numpy().view(H.RESULT_DTYPE)
     out, o = [], 0
@@ -115,14 +118,116 @@ def test_parse_with_sign_hiding_matches_the_oracle(hip):
             assert np.array_equal(got[s][k][:he, :we], want[k][:he, :we]), (s, k)
 
 
+def _ts_block(rng, w, h, kind):
+    c = ((rng.random((h, w)) < [0.3, 1.0, 0.8, 0.05][kind]) *
+         rng.integers(-[4, 40, 3, 3000][kind], [4, 40, 3, 3000][kind] + 1, (h, w))).astype(np.int32)
+    if not c.any():
+        c[rng.integers(0, h), rng.integers(0, w)] = 1
+    return c
+
+
+def build_mixed(rng, n_sub, qps, max_blocks=14):
+    """Substreams that mix regular blocks (transform_skip_flag absent or coded 0) with transform-skip blocks (flag coded 1,
+    not coded, BDPCM); dependent quantisation per block; no sign hiding, so every block must come back exactly."""
+    orc = H.load_oracle()
+    sizes = [1, 2, 4, 8, 16, 32]
+    subs = []
+    for s in range(n_sub):
+        blocks, metas = [], []
+        for k in range(int(rng.integers(1, max_blocks + 1))):
+            kind = int(rng.integers(0, 5))
+            dq = int(rng.integers(0, 2))
+            if kind < 2:
+                w, h = SHAPES[int(rng.integers(0, len(SHAPES)))]
+                if kind == 1:
+                    w, h = min(w, 32), min(h, 32)
+                c = H.random_block(rng, w, h, density=float(rng.choice([0.1, 0.5, 1.0])), big=float(rng.choice([0.0, 0.2])))
+                fl = dq | (H.TU_TS_FLAG if kind == 1 else 0)
+            else:
+                w, h = sizes[int(rng.integers(0, 6))], sizes[int(rng.integers(0, 6))]
+                if w * h == 1:
+                    h = 4
+                c = _ts_block(rng, w, h, int(rng.integers(0, 4)))
+                fl = dq | H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, 0, H.TU_BDPCM][kind - 2]
+            blocks.append(c)
+            metas.append((w, h, int(rng.integers(0, 2)), fl))
+        rec = np.concatenate([orc.residual_records(c, metas[i][2], metas[i][3])[0] for i, c in enumerate(blocks)] + [np.array([0x81FF], np.uint16)])
+        data, _ = orc.encode_records(rec, int(qps[s]), 2, 3)
+        subs.append((metas, blocks, data))
+    return subs
+
+
+def test_transform_skip_and_regular_blocks_mixed(hip):
+    """residual_codingTS / BDPCM / ts_flag on the device: coded blocks come back exactly, bit counts and the per-block info
+    (scanPosLast | MTS violation, or TS) equal the oracle's (pinned to the reference reader in tests/test_residual_oracle.py)."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(0x7511)
+    n_sub = 160
+    qps = rng.integers(0, 64, n_sub)
+    subs = build_mixed(rng, n_sub, qps)
+    got, res = parse(hip, subs, qps)
+    info = parse.last_info
+    assert not res["flags"].any()
+    t = 0
+    for s, (metas, blocks, data) in enumerate(subs):
+        rc, want, nbits, winfo = orc.residual_decode(data, int(qps[s]), metas, with_info=True)
+        assert rc == 0 and int(res["n_bits"][s]) == nbits, s
+        for k, c in enumerate(blocks):
+            we, he = min(metas[k][0], 32), min(metas[k][1], 32)
+            assert np.array_equal(got[s][k][:he, :we], c[:he, :we]), (s, k, metas[k])
+            assert int(info[t]) == int(winfo[k]), (s, k, metas[k], hex(int(info[t])), hex(int(winfo[k])))
+            t += 1
+
+
+def test_transform_skip_budget_exhaustion_and_escapes(hip):
+    """Saturated transform-skip blocks: the 7/4 bins-per-sample budget runs out (bypass levels with bypass signs), 32-bin
+    escape codes; with the flag in the stream, without, and with BDPCM."""
+    subs, qps = [], []
+    orc = H.load_oracle()
+    for w, h in [(4, 4), (32, 32), (8, 16), (2, 2), (1, 16), (16, 1)]:
+        for v in (1, -7, 2000, -32768):
+            c = np.full((h, w), v, np.int32)
+            c[::2, 1::2] = -v if v != -32768 else 32767
+            for fl in (H.TU_TRANSFORM_SKIP | H.TU_TS_FLAG, H.TU_TRANSFORM_SKIP | H.TU_BDPCM, H.TU_TRANSFORM_SKIP):
+                metas = [(w, h, 0, fl), (w, h, 1, fl)]
+                rec = np.concatenate([orc.residual_records(c, m[2], m[3])[0] for m in metas] + [np.array([0x81FF], np.uint16)])
+                data, _ = orc.encode_records(rec, 30, 2, 3)
+                subs.append((metas, [c, c], data))
+                qps.append(30)
+    got, res = parse(hip, subs, np.array(qps))
+    assert not res["flags"].any()
+    for s, (metas, blocks, data) in enumerate(subs):
+        rc, want, nbits = orc.residual_decode(data, 30, metas)
+        assert rc == 0 and int(res["n_bits"][s]) == nbits
+        for k in range(2):
+            assert np.array_equal(got[s][k], blocks[k]), (s, k, metas[k])
+
+
+def test_ts_flag_in_the_stream_decides(hip):
+    """A block whose descriptor only says "transform_skip_flag is coded" is parsed as the decoded bin says — the real
+    decoder's situation (cabac_reader.cpp:2737-2752) — whatever its TRANSFORM_SKIP bit claims."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(99)
+    c_ts, c_reg = _ts_block(rng, 8, 8, 1), H.random_block(rng, 8, 8, density=0.6)
+    coded = [(8, 8, 0, H.TU_TS_FLAG | H.TU_TRANSFORM_SKIP), (8, 8, 0, H.TU_TS_FLAG)]
+    rec = np.concatenate([orc.residual_records(c_ts, 0, coded[0][3])[0], orc.residual_records(c_reg, 0, coded[1][3])[0], np.array([0x81FF], np.uint16)])
+    data, _ = orc.encode_records(rec, 28, 2, 3)
+    lying = [(8, 8, 0, H.TU_TS_FLAG), (8, 8, 0, H.TU_TS_FLAG | H.TU_TRANSFORM_SKIP)]   # descriptor bits swapped
+    got, res = parse(hip, [(lying, [c_ts, c_reg], data)], np.array([28]))
+    assert not res["flags"].any()
+    assert np.array_equal(got[0][0], c_ts) and np.array_equal(got[0][1], c_reg)
+    assert int(parse.last_info[0]) == H.TU_INFO_TS and not (int(parse.last_info[1]) & H.TU_INFO_TS)
+
+
 def test_parse_error_flags(hip):
     rng = np.random.default_rng(3)
     qps = np.full(6, 30)
     subs = build(rng, 6, lambda s: 0, qps, max_blocks=4)
-    # 0: intact; 1: truncated input; 2: stop pattern destroyed; 3: a transform-skip block (not covered); 4, 5: intact
+    # 0: intact; 1: truncated input; 2: stop pattern destroyed; 3: a transform-skip block beyond 32 x 32 (not covered); 4, 5: intact
     caps = [len(s[2]) for s in subs]
     caps[1] = max(1, caps[1] // 3)
-    subs[3] = ([(m[0], m[1], m[2], H.TU_TRANSFORM_SKIP) if i == 0 else m for i, m in enumerate(subs[3][0])], subs[3][1], subs[3][2])
+    subs[3] = ([(64, 16, m[2], H.TU_TRANSFORM_SKIP) if i == 0 else m for i, m in enumerate(subs[3][0])],
+               [np.zeros((16, 64), np.int32) if i == 0 else c for i, c in enumerate(subs[3][1])], subs[3][2])
 
     def mutate(buf, desc):
         o = int(desc["byte_offset"][2]) + len(subs[2][2]) - 1
@@ -155,7 +260,21 @@ def test_golden_substreams_from_the_reference_reader(hip):
         subs.append((metas, blocks, g["s%d_bytes" % s]))
         qps.append(int(g["s%d_qp" % s][0]))
     got, res = parse(hip, subs, np.array(qps))
+    info = parse.last_info
     assert not res["flags"].any()
+    t = 0
+    for s in range(n_sub):    # mtsIdx / CUCtx as the reference reader left them (ref_residual_decode's info)
+        for k, m in enumerate(subs[s][0]):
+            ts, lfnst_viol, lfnst_last, mts_viol, mts_last = (int(x) for x in g["s%d_refinfo" % s][k])
+            w, h, chroma = m[0], m[1], m[2]
+            word = int(info[t])
+            t += 1
+            assert bool(word & H.TU_INFO_TS) == bool(ts), (s, k)
+            if not ts:
+                last, big = word & 0xFFFF, w >= 4 and h >= 4
+                assert lfnst_viol == (int(big and last > (7 if (w, h) in ((4, 4), (8, 8)) else 15)) << (1 if chroma else 0))
+                assert lfnst_last == int(big and last >= 1) and mts_last == int((not chroma) and last >= 1)
+                assert mts_viol == int(bool(word & H.TU_INFO_MTS_VIOLATION))
     for s in range(n_sub):
         assert int(res["n_bits"][s]) == int(g["s%d_qp" % s][1])
         for k, c in enumerate(subs[s][1]):
