@@ -219,6 +219,10 @@ def end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins, reps=3):
     return out
 
 
+def n_coef_total(c_u, copies):
+    return c_u * copies
+
+
 def residual_leg(hip, n_tiles, unique=256, reps=4):
     """Coefficient blocks -> bin records (cabac_hip_residual_device), both passes, on n_tiles tiles of
     workload.RESIDUAL_TILE_MIX (`unique` generated tiles, replicated on the device).  Checked against the md5 the
@@ -297,20 +301,21 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
     ok = ok and round_trip
     out_bytes = int(((res["n_bits"].astype(np.int64) + 7) // 8).sum())
     # ... and back: the residual parser turns the bytes into coefficient blocks again, deriving every context itself.
-    # The workload codes with sign-data hiding, which leaves one sign per group to the parity of the level sum (an
-    # encoder's quantiser arranges that; random blocks do not), so the magnitudes are what must come back exactly.
+    # The workload codes with sign-data hiding and its hidden signs are arranged as an encoder's quantiser leaves them
+    # (workload._arrange_hidden_signs), so every coefficient must come back exactly.
     t_first = (torch.arange(n_tiles + 1, device="cuda", dtype=torch.int32) * per_tile).contiguous()
     t_dec = torch.zeros_like(t_co)
     t_res_p = torch.zeros(2 * n_tiles, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    hip.profile_enable(3)
-    for _ in range(3):
+    hip.profile_enable(reps + 1)
+    for _ in range(reps + 1):
         hip.residual_parse_device(n_tiles, t_ddesc.data_ptr(), t_bytes.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(),
                                   t_dec.data_ptr(), t_res_p.data_ptr())
     parse_ms = float(np.mean([ms for kk, ms in hip.profile_read() if kk == 9][1:]))
     res_p = t_res_p.cpu().numpy().view(capi.RESULT_DTYPE)
     parsed_back = (not res_p["flags"].any() and bool(np.array_equal(res_p["n_bits"], t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)["n_bits"]))
-                   and bool(torch.equal(t_dec.abs(), t_co.abs())))
+                   and bool(torch.equal(t_dec, t_co)))
+    bytes_p = out_bytes + 4 * n_coef_total(c_u, copies) + (16 + 8) * n + 40 * n_tiles
     ok = ok and parsed_back
     n_coef = c_u * copies
     bytes1 = 4 * n_coef + (16 + 4 + 4) * n
@@ -331,7 +336,9 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
             # bytes -> coefficients by the residual parser (contexts derived on the device, nothing supplied but block sizes)
             "parse": {"kernel": "residual_parse_kernel", "kernel_ms": round(parse_ms, 4),
                       "mbins_s": round(n_bins / (parse_ms * 1e-3) / 1e6, 1), "mcoeff_s": round(n_coef / (parse_ms * 1e-3) / 1e6, 1),
-                      "magnitudes_match": bool(parsed_back)},
+                      "algorithmic_bytes_per_launch": bytes_p, "achieved_gbps": round(bytes_p / (parse_ms * 1e-3) / 1e9, 2),
+                      "frac_of_hbm_peak": round(bytes_p / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                      "coefficients_match": bool(parsed_back)},
             "records_match_reference": bool(ok)}
 
 
