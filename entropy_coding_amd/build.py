@@ -15,6 +15,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libcabac_hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-I" + HOST]
+FLAGS += os.environ.get("CABAC_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DCABAC_PARSE_PROFILE)
 
 
 def library_path():

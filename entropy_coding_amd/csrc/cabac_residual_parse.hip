@@ -40,6 +40,16 @@
 
 namespace cabac {
 
+#ifdef CABAC_PARSE_PROFILE  // build with CABAC_EXTRA_FLAGS=-DCABAC_PARSE_PROFILE: where wave 0 of workgroup 0 spends its cycles
+__device__ unsigned long long g_parse_prof[16];
+#define PP_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PP_ADD(slot, t0, t1) \
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_parse_prof[slot] += (t1) - (t0)
+#else
+#define PP_TICK(var)
+#define PP_ADD(slot, t0, t1)
+#endif
+
 namespace {
 
 constexpr uint32_t kCtxStride = 380;   // contexts per wave (379 + pad), two words each
@@ -290,6 +300,7 @@ __device__ __forceinline__ uint32_t sig_set_base(uint32_t set) { return (uint32_
 __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
                                                   uint32_t lane) {
   const uint32_t chroma = g.chroma, j = lane & 15u;
+  PP_TICK(p0);
   // ---- last significant position (cabac_reader.cpp:2865-2938)
   const uint32_t luma_off_x = g.lw < 3u ? 0u : g.lw == 3u ? 3u : g.lw == 4u ? 6u : g.lw == 5u ? 10u : 15u;
   const uint32_t luma_off_y = g.lh < 3u ? 0u : g.lh == 3u ? 3u : g.lh == 4u ? 6u : g.lh == 5u ? 10u : 15u;
@@ -324,7 +335,10 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
   uint32_t state = 0;
   int32_t budget = (int32_t)((g.we * g.he * 28u) >> 4);
   uint64_t sig_map = 0;
+  PP_TICK(p1);
+  PP_ADD(1, p0, p1);
   for (int32_t cg = (int32_t)last_cg; cg >= 0; cg--) {
+    PP_TICK(c0);
     const uint32_t gp = rl(gl, (uint32_t)cg), gx = gp & 15u, gy = gp >> 4, gbit = gy * g.wg + gx;
     bool sig = cg == (int32_t)last_cg || cg == 0;
     if (!sig) {  // coded_sub_block_flag (cabac_reader.cpp:2965-2975)
@@ -333,6 +347,8 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
       pd_check(d);
       sig = pd_bin(d, ctx2, CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)) != 0u;
     }
+    PP_TICK(c1);
+    PP_ADD(2, c0, c1);
     if (!sig) continue;
     sig_map |= 1ull << gbit;
     if (!chroma && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;  // cabac_reader.cpp:2729-2732
@@ -359,6 +375,8 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
     const int32_t infer_i = is_last_cg ? (int32_t)last_i : (cg != 0 ? 0 : -1);
     uint32_t nz_mask = 0, g2_mask = 0, lev = 0;
     int32_t i = first_i;
+    PP_TICK(c2);
+    PP_ADD(3, c1, c2);
     // ---- pass 1: sig / gt1 / parity / gt2 while the budget of context-coded bins lasts (cabac_reader.cpp:3007-3063)
     for (; i >= 0 && budget >= 4; i--) {
       pd_check(d);
@@ -393,6 +411,14 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
       state = (trans >> ((state << 2) + ((level & 1u) << 1))) & 3u;
     }
     const int32_t bypass_i = i;  // positions bypass_i .. 0 are coded without contexts
+    PP_TICK(c3);
+    PP_ADD(4, c2, c3);
+#ifdef CABAC_PARSE_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_parse_prof[10] += (unsigned)(first_i - i);                 // positions visited in pass 1
+      g_parse_prof[11] += 1;                                       // coded groups
+    }
+#endif
     // ---- pass 2: remainders of the context-coded levels (:3065-3077)
     for (uint32_t m = g2_mask; m != 0u;) {
       const uint32_t q = 31u - (uint32_t)__builtin_clz(m);
@@ -414,6 +440,8 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
         t_abs += (0u - ((in_tmpl >> q) & 1u)) & v;
       }
     }
+    PP_TICK(c4);
+    PP_ADD(5, c3, c4);
     // ---- signs; with sign-data hiding the lowest position's sign is the parity of the level sum (:3100-3126)
     const uint32_t n_nz = (uint32_t)__builtin_popcount(nz_mask);
     const int32_t first_nz = nz_mask ? (int32_t)__builtin_ctz(nz_mask) : first_i;
@@ -428,6 +456,8 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
       const uint32_t neg = k < n_signs ? (pattern >> (n_signs - 1u - k)) & 1u : odd;
       if (mine) blk[(y << g.lwe) + x] = neg ? -(int32_t)lev : (int32_t)lev;
     }
+    PP_TICK(c5);
+    PP_ADD(6, c4, c5);
   }
   return info;
 }
@@ -600,7 +630,9 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
   uint32_t flags_out = 0;
 
   const uint32_t t_end = tile_first[sub + 1];
+  PP_TICK(k0);
   for (uint32_t t = tile_first[sub]; t < t_end; t++) {
+    PP_TICK(b0);
     const cabac_tu_desc tu = tus[t];
     BlockGeom g;
     const uint32_t lw = tu.log2_width, lh = tu.log2_height;
@@ -623,9 +655,12 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
       break;
     }
     uint32_t info = CABAC_TU_INFO_TS;
+    PP_TICK(b1);
+    PP_ADD(0, b0, b1);
     if (ts) parse_ts(d, ctx2, blk, tab, g, lane);
     else info = parse_regular(d, ctx2, blk, tab, g, lane);
     if (tu_info && lane == 0u) tu_info[t] = info;
+    PP_TICK(b2);
     // the finished block goes out row by row (all lanes), the LDS copy is cleared for the next block
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -638,7 +673,14 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PP_TICK(b3);
+    PP_ADD(7, b2, b3);
+#ifdef CABAC_PARSE_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_parse_prof[12] += 1;  // blocks
+#endif
   }
+  PP_TICK(k1);
+  PP_ADD(8, k0, k1);
 
   // encodeBinTrm(1) closes the substream (cabac_writer.cpp:104-107); decodeBinTrm, arith_codec.cpp:181-197
   uint32_t trm = 1;
@@ -674,6 +716,15 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     results[sub] = r;
   }
 }
+
+#ifdef CABAC_PARSE_PROFILE
+hipError_t debug_read_parse_prof(unsigned long long *out) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_parse_prof), sizeof(unsigned long long) * 16);
+  unsigned long long zero[16] = {};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_parse_prof), zero, sizeof zero);
+  return e;
+}
+#endif
 
 hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
                                  const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff, uint32_t *tu_info,
