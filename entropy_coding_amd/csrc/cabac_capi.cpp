@@ -19,6 +19,13 @@
 #include "cabac_hip.h"
 #include "cabac_kernels.h"
 
+#ifdef CABAC_PARSE_PROFILE
+namespace cabac {
+hipError_t debug_read_parse_prof(unsigned long long *out);
+hipError_t debug_read_parse_waves(unsigned long long *out);
+}
+#endif
+
 struct cabac_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -922,7 +929,7 @@ int cabac_hip_host_unregister(void *p) {
 int cabac_hip_host_is_pinned(const void *p, size_t bytes) { return host_is_pinned(p, bytes) ? 1 : 0; }
 
 #ifdef CABAC_PARSE_PROFILE
-namespace cabac { hipError_t debug_read_parse_prof(unsigned long long *out); }
+int cabac_hip_debug_parse_waves(unsigned long long *out) { return cabac::debug_read_parse_waves(out) == hipSuccess ? 0 : -3; }
 int cabac_hip_debug_parse_prof(unsigned long long *out) { return cabac::debug_read_parse_prof(out) == hipSuccess ? 0 : -3; }
 #endif
 

@@ -42,6 +42,7 @@ namespace cabac {
 
 #ifdef CABAC_PARSE_PROFILE  // build with CABAC_EXTRA_FLAGS=-DCABAC_PARSE_PROFILE: where wave 0 of workgroup 0 spends its cycles
 __device__ unsigned long long g_parse_prof[16];
+__device__ unsigned long long g_parse_wave[3 * 8192];  // per substream: start, end (memtime), HW_ID | XCC_ID << 32
 #define PP_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PP_ADD(slot, t0, t1) \
   if (blockIdx.x == 0 && threadIdx.x == 0) g_parse_prof[slot] += (t1) - (t0)
@@ -52,8 +53,15 @@ __device__ unsigned long long g_parse_prof[16];
 
 namespace {
 
-constexpr uint32_t kCtxStride = 380;   // contexts per wave (379 + pad), two words each
+// The parser only ever touches the residual-coding contexts: SigCoeffGroup .. LastY (ids 86..291), TransformSkipFlag
+// (310, 311) and the transform-skip sets (357..378): 230 slots of 16 bytes {state, shifts, adds, -} per wave.
+constexpr uint32_t kCtxSlots = 232;
 constexpr uint32_t kBlkWords = 1024;   // coded region of a block, pitch = its coded width
+__host__ __device__ constexpr uint32_t slot_of(uint32_t id) { return id < 292u ? id - 86u : id < 312u ? id - 310u + 206u : id - 357u + 208u; }
+__device__ __forceinline__ uint32_t id_of_slot(uint32_t s) { return s < 206u ? s + 86u : s < 208u ? s - 206u + 310u : s - 208u + 357u; }
+#define SL_A(id) ((id) - 86u)            /* ids 86..291 */
+#define SL_TS(id) ((id) - 357u + 208u)   /* ids 357..378 */
+#define SL_TS_FLAG(ch) (206u + (ch))
 
 // Per coefficient-group shape: which scan positions of the group lie in the five-sample template of each position
 // (context_modelling.hpp:71-117: right, right+1, below-right, below, below+1), and for transform-skip blocks the
@@ -141,40 +149,37 @@ __device__ __forceinline__ void pd_check(PDec &d) {
   d.look = look;
 }
 
-// decodeBin, arith_codec.cpp:242-277, with BinProbModel_Std::getLPS / update (contexts.cpp:903-913, :939-954).  ctx2[id]
-// = {s0 | s1 << 16 (rate bits cleared), shift0 | shift1 << 16}.  Branch-free: the one data-dependent decision of the
-// walk is taken on the returned bin.
-__device__ __forceinline__ uint32_t pd_bin(PDec &d, uint2 *ctx2, uint32_t id) {
+// decodeBin, arith_codec.cpp:242-277, with BinProbModel_Std::getLPS / update (contexts.cpp:903-913, :939-954).
+// ctx[slot] = {s0 | s1 << 16 (rate bits cleared), shift0 | shift1 << 16, add0 | add1 << 16, -}.  Branch-free: the one
+// data-dependent decision of the walk is taken on the returned bin.  The walk is bound by instruction issue, so this is
+// written for count: 31 vector instructions, two LDS accesses and the one v_readfirstlane.
+__device__ __forceinline__ uint32_t pd_bin(PDec &d, uint4 *ctx, uint32_t slot) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  const uint2 e = ctx2[id];
+  const uint4 e = ctx[slot];
   const uint32_t st = e.x;
   const uint32_t sum = (st & 0xffffu) + (st >> 16);
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
-  const uint32_t t = (__umul24(d.range >> 5, k) >> 1) + 4u;
+  const uint32_t t = (__umul24(d.range >> 5, k) + 8u) >> 1;     // ((range >> 5) * k >> 1) + 4
   const uint32_t rm = d.range - t;
   const uint32_t ev = d.hi - (rm << 22);                        // value - scaledRange
-  const uint32_t ngem = (uint32_t)((int32_t)ev >> 31);          // ~0: MPS path
-  const uint32_t bin = ~(ngem ^ sx) & 1u;
-  const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;         // getRenormBitsLPS
-  const uint32_t nm = ngem & ~(rm >> 8) & 1u;                   // MPS path renormalises by one bit iff rm < 256
-  const uint32_t nsh = (~ngem & nl) | nm;
-  d.hi = (d.hi & ngem) | (ev & ~ngem);
-  d.range = ((rm & ngem) | (t & ~ngem)) << nsh;
+  const bool mps = (int32_t)ev < 0;
+  const uint32_t bin = (mps ? sx : ~sx) & 1u;
+  // renormalisation: LPS by getRenormBitsLPS = clz(t) - 23, MPS by one bit iff rm < 256 (rm < 512)
+  const uint32_t nsh = mps ? (rm >> 8) ^ 1u : (uint32_t)__builtin_clz(t) - 23u;
+  d.hi = mps ? d.hi : ev;
+  d.range = (mps ? rm : t) << nsh;
   const uint64_t v = (((uint64_t)d.hi << 32) | d.lo) << nsh;
   d.hi = (uint32_t)(v >> 32);
   d.lo = (uint32_t)v;
   d.look -= (int32_t)nsh;
   // update(bin) on both 15-bit estimators at once
-  const u16x2 sh2 = __builtin_bit_cast(u16x2, e.y);
-  const u16x2 mask2 = __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
   const u16x2 st2 = __builtin_bit_cast(u16x2, st);
-  const u16x2 add2 = (__builtin_bit_cast(u16x2, 0x7fff7fffu) >> sh2) & mask2;
-  const u16x2 rest2 = st2 - ((st2 >> sh2) & mask2);
-  const uint32_t a_v = __builtin_bit_cast(uint32_t, add2), rest = __builtin_bit_cast(uint32_t, rest2);
+  const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, e.y)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
+  const uint32_t rest = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2));
   uint32_t upd;
-  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(a_v), "v"(bin), "v"(rest));
-  ctx2[id].x = upd;
+  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(e.z), "v"(bin), "v"(rest));
+  ctx[slot].x = upd;
   return rfl(bin);
 }
 
@@ -297,7 +302,7 @@ __device__ __forceinline__ int32_t blk_val(const int32_t *blk, const BlockGeom &
 __device__ __forceinline__ uint32_t sig_set_base(uint32_t set) { return (uint32_t)((0x8E827A6E665Aull >> (8u * set)) & 0xffu); }
 
 // ---- regular residual coding: one block (after ts_flag) -----------------------------------------------------------
-__device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
+__device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
                                                   uint32_t lane) {
   const uint32_t chroma = g.chroma, j = lane & 15u;
   PP_TICK(p0);
@@ -310,11 +315,11 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
   uint32_t px = 0, py = 0;
   for (; px < max_x; px++) {
     pd_check(d);
-    if (!pd_bin(d, ctx2, CABAC_CTX_LAST_X(chroma) + off_x + (px >> sh_x))) break;
+    if (!pd_bin(d, ctx, SL_A(CABAC_CTX_LAST_X(chroma)) + off_x + (px >> sh_x))) break;
   }
   for (; py < max_y; py++) {
     pd_check(d);
-    if (!pd_bin(d, ctx2, CABAC_CTX_LAST_Y(chroma) + off_y + (py >> sh_y))) break;
+    if (!pd_bin(d, ctx, SL_A(CABAC_CTX_LAST_Y(chroma)) + off_y + (py >> sh_y))) break;
   }
   if (px > 3u) px = min_in_group(px) + pd_bins_ep(d, (px - 2u) >> 1);
   if (py > 3u) py = min_in_group(py) + pd_bins_ep(d, (py - 2u) >> 1);
@@ -331,12 +336,21 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
   uint32_t info = (last_cg << g.cg_l2) + last_i;
 
   const uint32_t in_tmpl = tab.in_template[g.cgw_l2][g.cgh_l2][j];
-  const uint32_t trans = (g.fl & CABAC_TU_DEP_QUANT) ? 32040u : 0u;  // cabac_reader.cpp:2699-2700
-  uint32_t state = 0;
+  // dependent-quantisation state (cabac_reader.cpp:2699-2700: table 32040): kept as sq = 8 * state, the bit offset of the
+  // state's SigFlag context slot in a lane's packed word; the transition table holds the next sq for (state, parity)
+  const uint64_t trans8 = (g.fl & CABAC_TU_DEP_QUANT) ? 0x0818180800101000ull : 0ull;  // byte [2 * state + parity] = 8 * next state: 0,2 | 2,0 | 1,3 | 3,1
+  // SigFlag slots by state (sets: state 0, 1 -> 0; 2 -> 1; 3 -> 2; luma sets 0, 2, 4 / chroma 1, 3, 5), packed one byte each
+  const uint32_t sb0 = SL_A(CABAC_CTX_SIG_FLAG(0)), sb1 = SL_A(CABAC_CTX_SIG_FLAG(1)), sb2 = SL_A(CABAC_CTX_SIG_FLAG(2)),
+                 sb3 = SL_A(CABAC_CTX_SIG_FLAG(3)), sb4 = SL_A(CABAC_CTX_SIG_FLAG(4)), sb5 = SL_A(CABAC_CTX_SIG_FLAG(5));
+  const uint32_t sig_bases = chroma ? (sb1 | sb1 << 8 | sb3 << 16 | sb5 << 24) : (sb0 | sb0 << 8 | sb2 << 16 | sb4 << 24);
+  const uint32_t gt1_base = SL_A(CABAC_CTX_GTX_FLAG(2u + chroma)), par_base = SL_A(CABAC_CTX_PAR_FLAG(chroma)),
+                 gt2_base = SL_A(CABAC_CTX_GTX_FLAG(chroma));
+  uint32_t sq = 0;
   int32_t budget = (int32_t)((g.we * g.he * 28u) >> 4);
   uint64_t sig_map = 0;
   PP_TICK(p1);
   PP_ADD(1, p0, p1);
+  const uint32_t pitch = 1u << g.lwe;
   for (int32_t cg = (int32_t)last_cg; cg >= 0; cg--) {
     PP_TICK(c0);
     const uint32_t gp = rl(gl, (uint32_t)cg), gx = gp & 15u, gy = gp >> 4, gbit = gy * g.wg + gx;
@@ -345,70 +359,89 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
       const uint32_t right = gx + 1u < g.wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
       const uint32_t below = gy + 1u < g.hg ? (uint32_t)(sig_map >> (gbit + g.wg)) & 1u : 0u;
       pd_check(d);
-      sig = pd_bin(d, ctx2, CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below)) != 0u;
+      sig = pd_bin(d, ctx, SL_A(CABAC_CTX_SIG_COEFF_GROUP(chroma)) + (right | below)) != 0u;
     }
     PP_TICK(c1);
     PP_ADD(2, c0, c1);
     if (!sig) continue;
     sig_map |= 1ull << gbit;
     if (!chroma && (gx > 3u || gy > 3u)) info |= CABAC_TU_INFO_MTS_VIOLATION;  // cabac_reader.cpp:2729-2732
-    // this lane's position and what its contexts need: the template over the groups decoded before (samples of this
-    // group still read as zero), the diagonal class offsets (context_modelling.hpp:119-143)
+    // This lane's position and what its contexts need (context_modelling.hpp:71-143): the template over the groups
+    // decoded before (samples of this group still read as zero) — sc the clipped sum, dd = sc minus the count of non-zero
+    // neighbours, t_abs the plain sum — and the diagonal class offsets.
     const uint32_t x = (gx << g.cgw_l2) + ix, y = (gy << g.cgh_l2) + iy, diag = x + y;
-    uint32_t t_abs = 0, t_pk = 0;  // t_pk: clipped sum | non-zero count << 8 | sig class offset << 12 | abs class offset << 20
+    uint32_t t_abs, sc, dd, sig_cls, abs_cls1;
     {
-      const uint32_t a0 = blk_abs(blk, g, x + 1u, y), a1 = blk_abs(blk, g, x + 2u, y), a2 = blk_abs(blk, g, x + 1u, y + 1u),
-                     a3 = blk_abs(blk, g, x, y + 1u), a4 = blk_abs(blk, g, x, y + 2u);
+      const uint32_t at = (y << g.lwe) + x;
+      const bool x1 = x + 1u < g.we, x2 = x + 2u < g.we, y1 = y + 1u < g.he, y2 = y + 2u < g.he;
+      auto mag = [&](bool in, uint32_t idx) {
+        const int32_t v = blk[in ? idx : 0u];
+        return in ? (uint32_t)(v < 0 ? -v : v) : 0u;
+      };
+      const uint32_t a0 = mag(x1, at + 1u), a1 = mag(x2, at + 2u), a2 = mag(x1 && y1, at + pitch + 1u), a3 = mag(y1, at + pitch),
+                     a4 = mag(y2, at + 2u * pitch);
       t_abs = a0 + a1 + a2 + a3 + a4;
       auto clip = [](uint32_t a) { return min(a, 4u + (a & 1u)); };
-      t_pk = clip(a0) + clip(a1) + clip(a2) + clip(a3) + clip(a4);
-      t_pk += ((uint32_t)(a0 != 0u) + (uint32_t)(a1 != 0u) + (uint32_t)(a2 != 0u) + (uint32_t)(a3 != 0u) + (uint32_t)(a4 != 0u)) << 8;
-      uint32_t sig_cls = diag < 2u ? 4u : 0u;
+      sc = clip(a0) + clip(a1) + clip(a2) + clip(a3) + clip(a4);
+      dd = sc - ((uint32_t)(a0 != 0u) + (uint32_t)(a1 != 0u) + (uint32_t)(a2 != 0u) + (uint32_t)(a3 != 0u) + (uint32_t)(a4 != 0u));
+      sig_cls = diag < 2u ? 4u : 0u;
       if (!chroma) sig_cls += diag < 5u ? 4u : 0u;
-      uint32_t abs_cls = 0;
-      if (diag == 0u) abs_cls = chroma ? 5u : 15u;
-      else if (!chroma) abs_cls = diag < 3u ? 10u : diag < 10u ? 5u : 0u;
-      t_pk |= (sig_cls << 12) | (abs_cls << 20);
+      abs_cls1 = 1u;
+      if (diag == 0u) abs_cls1 += chroma ? 5u : 15u;
+      else if (!chroma) abs_cls1 += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
     }
+    // per lane, kept up to date by the lanes themselves: the SigFlag slot of this position for each state (one byte each)
+    // and the offset of its gt1 / parity / gt2 contexts — the serial walk reads them with one v_readlane each
+    auto sig_slots = [&]() {
+      const uint32_t o = min((sc + 1u) >> 1, 3u) + sig_cls;
+      const uint32_t o2 = o | (o << 8);
+      return sig_bases + (o2 | (o2 << 16));
+    };
+    uint32_t sig4 = sig_slots(), aofs_v = min(dd, 4u) + abs_cls1;
     const bool is_last_cg = cg == (int32_t)last_cg;
     const int32_t first_i = is_last_cg ? (int32_t)last_i : (int32_t)g.cg_size - 1;
-    const int32_t infer_i = is_last_cg ? (int32_t)last_i : (cg != 0 ? 0 : -1);
     uint32_t nz_mask = 0, g2_mask = 0, lev = 0;
     int32_t i = first_i;
     PP_TICK(c2);
     PP_ADD(3, c1, c2);
     // ---- pass 1: sig / gt1 / parity / gt2 while the budget of context-coded bins lasts (cabac_reader.cpp:3007-3063)
-    for (; i >= 0 && budget >= 4; i--) {
+    // The first position of the group's walk is special (the last significant position of the block: significant by
+    // definition, context offset 0) and so is its last (significance inferred when nothing before it was significant and
+    // the group flag was coded): both are peeled off the loop's common path by `special`.
+    const int32_t infer_i = is_last_cg ? (int32_t)last_i : (cg != 0 ? 0 : -1);
+    while (i >= 0 && budget >= 4) {
       pd_check(d);
-      const uint32_t s = rl(t_pk, (uint32_t)i);
-      const uint32_t sum_clip = s & 0xffu, n_t = (s >> 8) & 0xfu;
-      uint32_t sf = (nz_mask == 0u && i == infer_i) ? 1u : 0u;
-      if (!sf) {
-        const uint32_t set = chroma + 2u * (state > 1u ? state - 1u : 0u);
-        sf = pd_bin(d, ctx2, sig_set_base(set) + min((sum_clip + 1u) >> 1, 3u) + ((s >> 12) & 0xffu));
+      uint32_t sf = 1u;
+      const bool special = i == infer_i;
+      if (!(special && nz_mask == 0u)) {
+        sf = pd_bin(d, ctx, (rl(sig4, (uint32_t)i) >> sq) & 0xffu);
         budget--;
       }
-      uint32_t level = 0;
+      uint32_t par2 = 0;  // 2 * parity of the level
       if (sf) {
-        const bool at_last = is_last_cg && i == (int32_t)last_i;
-        const uint32_t aofs = at_last ? 0u : min(sum_clip - n_t, 4u) + 1u + (s >> 20);
-        const uint32_t g1 = pd_bin(d, ctx2, CABAC_CTX_GTX_FLAG(2u + chroma) + aofs);
-        uint32_t par = 0, g2 = 0;
+        const uint32_t aofs = (is_last_cg && i == (int32_t)last_i) ? 0u : rl(aofs_v, (uint32_t)i);
+        uint32_t level = 1u;
         budget--;
-        if (g1) {
-          par = pd_bin(d, ctx2, CABAC_CTX_PAR_FLAG(chroma) + aofs);
-          g2 = pd_bin(d, ctx2, CABAC_CTX_GTX_FLAG(chroma) + aofs);
+        if (pd_bin(d, ctx, gt1_base + aofs)) {
+          const uint32_t par = pd_bin(d, ctx, par_base + aofs);
+          const uint32_t g2 = pd_bin(d, ctx, gt2_base + aofs);
           budget -= 2;
+          level = 2u + par + (g2 << 1);
+          g2_mask |= g2 << i;
         }
-        level = 1u + par + g1 + (g2 << 1);
+        par2 = (level & 1u) << 1;
         nz_mask |= 1u << i;
-        g2_mask |= g2 << i;
         lev = j == (uint32_t)i ? level : lev;
-        const uint32_t hit = 0u - ((in_tmpl >> i) & 1u);  // ~0 in the lanes whose template holds this position
-        t_pk += hit & (level | 0x100u);
+        // into the templates that hold this position, and their context offsets again
+        const uint32_t hit = 0u - ((in_tmpl >> i) & 1u);
+        sc += hit & level;
+        dd += hit & (level - 1u);
         t_abs += hit & level;
+        sig4 = sig_slots();
+        aofs_v = min(dd, 4u) + abs_cls1;
       }
-      state = (trans >> ((state << 2) + ((level & 1u) << 1))) & 3u;
+      sq = (uint32_t)(trans8 >> (2u * sq + 4u * par2)) & 0xffu;
+      i--;
     }
     const int32_t bypass_i = i;  // positions bypass_i .. 0 are coded without contexts
     PP_TICK(c3);
@@ -430,10 +463,10 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
     // ---- pass 3: whole levels in bypass mode (:3079-3098)
     for (int32_t q = bypass_i; q >= 0; q--) {
       const uint32_t rice = rice_of((int)rl(t_abs, (uint32_t)q), 0);
-      const uint32_t pos0 = (state < 2u ? 1u : 2u) << rice;
+      const uint32_t pos0 = (sq < 16u ? 1u : 2u) << rice;
       const uint32_t rem = pd_rem_abs(d, rice, g.max_log2);
       const uint32_t v = rem == pos0 ? 0u : (rem < pos0 ? rem + 1u : rem);
-      state = (trans >> ((state << 2) + ((v & 1u) << 1))) & 3u;
+      sq = (uint32_t)(trans8 >> (2u * sq + 8u * (v & 1u))) & 0xffu;
       if (v) {
         nz_mask |= 1u << q;
         lev = j == (uint32_t)q ? v : lev;
@@ -463,7 +496,7 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint2 *ctx2, int32_t 
 }
 
 // ---- transform-skip residual coding: one block (cabac_reader.cpp:3130-3339) ------------------------------------------
-__device__ __forceinline__ void parse_ts(PDec &d, uint2 *ctx2, int32_t *blk, const LdsTables &tab, const BlockGeom &g, uint32_t lane) {
+__device__ __forceinline__ void parse_ts(PDec &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g, uint32_t lane) {
   const uint32_t j = lane & 15u;
   const bool bdpcm = (g.fl & CABAC_TU_BDPCM) != 0u;
   const uint32_t ip = tab.in_cg[g.cgw_l2][g.cgh_l2][j];
@@ -480,7 +513,7 @@ __device__ __forceinline__ void parse_ts(PDec &d, uint2 *ctx2, int32_t *blk, con
       const uint32_t left = gx > 0u ? (uint32_t)(sig_map >> (gbit - 1u)) & 1u : 0u;
       const uint32_t above = gy > 0u ? (uint32_t)(sig_map >> (gbit - g.wg)) & 1u : 0u;
       pd_check(d);
-      sig = pd_bin(d, ctx2, CABAC_CTX_TS_SIG_COEFF_GROUP + left + above) != 0u;
+      sig = pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_SIG_COEFF_GROUP) + left + above) != 0u;
     }
     if (!sig) continue;
     sig_map |= 1ull << gbit;
@@ -501,19 +534,19 @@ __device__ __forceinline__ void parse_ts(PDec &d, uint2 *ctx2, int32_t *blk, con
       const uint32_t n_nb = (uint32_t)(left != 0) + (uint32_t)(above != 0);
       uint32_t sf = (n_nz == 0u && i == hi_i) ? 1u : 0u;
       if (!sf) {
-        sf = pd_bin(d, ctx2, CABAC_CTX_TS_SIG_FLAG + n_nb);
+        sf = pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_SIG_FLAG) + n_nb);
         budget--;
       }
       if (sf) {
         const int32_t sl = (left > 0) - (left < 0), sa = (above > 0) - (above < 0);
         uint32_t sctx = ((sl == 0 && sa == 0) || sl * sa < 0) ? 0u : (sl >= 0 && sa >= 0) ? 1u : 2u;
         if (bdpcm) sctx += 3u;
-        const uint32_t sign = pd_bin(d, ctx2, CABAC_CTX_TS_RESIDUAL_SIGN + sctx);
-        const uint32_t g1 = pd_bin(d, ctx2, CABAC_CTX_TS_LRG1_FLAG + (bdpcm ? 3u : n_nb));
+        const uint32_t sign = pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_RESIDUAL_SIGN) + sctx);
+        const uint32_t g1 = pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_LRG1_FLAG) + (bdpcm ? 3u : n_nb));
         budget -= 2;
         uint32_t par = 0;
         if (g1) {
-          par = pd_bin(d, ctx2, CABAC_CTX_TS_PAR_FLAG);
+          par = pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_PAR_FLAG));
           budget--;
         }
         sign_pattern |= sign << n_nz;
@@ -530,7 +563,7 @@ __device__ __forceinline__ void parse_ts(PDec &d, uint2 *ctx2, int32_t *blk, con
       for (int32_t cut = 2; cut <= 8; cut += 2)
         if (c >= cut) {
           pd_check(d);
-          c += (int32_t)(pd_bin(d, ctx2, CABAC_CTX_TS_GTX_FLAG + (uint32_t)(cut >> 1)) << 1);
+          c += (int32_t)(pd_bin(d, ctx, SL_TS(CABAC_CTX_TS_GTX_FLAG) + (uint32_t)(cut >> 1)) << 1);
           budget--;
         }
       put((uint32_t)i, c);
@@ -577,9 +610,12 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
                                                                   const cabac_tu_desc *__restrict__ tus, int32_t *__restrict__ coeff_all,
                                                                   uint32_t *__restrict__ tu_info,
                                                                   cabac_substream_result *__restrict__ results) {
-  __shared__ uint2 ctx_all[W * kCtxStride];
+  __shared__ uint4 ctx_all[W * kCtxSlots];
   __shared__ int32_t blk_all[W * kBlkWords];
   __shared__ LdsTables tab;
+  // Placement: the walk is bound by what the waves of a CU share (instruction issue, the scalar unit), so the waves must
+  // be spread evenly: with 33 KB of LDS per workgroup at most four fit on a CU, and a 4 096-substream batch is exactly
+  // four per CU (measured: 16 waves on every CU, 4 on every SIMD).
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   {  // scan / shape tables into LDS
     uint8_t *dst = reinterpret_cast<uint8_t *>(&tab);
@@ -596,15 +632,17 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
   }
   const uint32_t sub = rfl(blockIdx.x * W + wave);
   const bool live = sub < n_sub;
-  uint2 *ctx2 = ctx_all + wave * kCtxStride;
+  uint4 *ctx = ctx_all + wave * kCtxSlots;
   int32_t *blk = blk_all + wave * kBlkWords;
   const cabac_substream_desc dsc = desc[live ? sub : 0];
   {
     const int qp = dsc.qp < 0 ? 0 : (dsc.qp > 63 ? 63 : dsc.qp);
     const uint32_t iid = dsc.init_id & 3u;
-    for (uint32_t k = lane; k < (uint32_t)kNumCtx; k += 64u) {
-      const uint32_t packed = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
-      ctx2[k] = make_uint2(packed & ~31u, ((packed & 3u) + 2u) | ((((packed >> 2) & 7u) + 5u) << 16));
+    for (uint32_t k = lane; k < 230u; k += 64u) {
+      const uint32_t id = id_of_slot(k);
+      const uint32_t packed = ctx2_init(qp, c_init_tables[iid * kNumCtx + id], c_init_tables[3 * kNumCtx + id]);
+      const uint32_t r0 = (packed & 3u) + 2u, r1 = ((packed >> 2) & 7u) + 5u;
+      ctx[k] = make_uint4(packed & ~31u, r0 | (r1 << 16), ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16), 0u);
     }
     for (uint32_t k = lane; k < kBlkWords; k += 64u) blk[k] = 0;
   }
@@ -648,7 +686,7 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     uint32_t ts = (g.fl & CABAC_TU_TRANSFORM_SKIP) ? 1u : 0u;
     if (g.fl & CABAC_TU_TS_FLAG) {
       pd_check(d);
-      ts = pd_bin(d, ctx2, CABAC_CTX_TRANSFORM_SKIP_FLAG(g.chroma));
+      ts = pd_bin(d, ctx, SL_TS_FLAG(g.chroma));
     }
     if (ts && (lw > 5u || lh > 5u)) {
       flags_out |= CABAC_RES_BAD_RECORD;
@@ -657,8 +695,8 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     uint32_t info = CABAC_TU_INFO_TS;
     PP_TICK(b1);
     PP_ADD(0, b0, b1);
-    if (ts) parse_ts(d, ctx2, blk, tab, g, lane);
-    else info = parse_regular(d, ctx2, blk, tab, g, lane);
+    if (ts) parse_ts(d, ctx, blk, tab, g, lane);
+    else info = parse_regular(d, ctx, blk, tab, g, lane);
     if (tu_info && lane == 0u) tu_info[t] = info;
     PP_TICK(b2);
     // the finished block goes out row by row (all lanes), the LDS copy is cleared for the next block
@@ -681,6 +719,19 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
   }
   PP_TICK(k1);
   PP_ADD(8, k0, k1);
+#ifdef CABAC_PARSE_PROFILE
+  if (lane == 0u) {  // spread of the waves' walk times, and when (after the first wave's start) the last one ended
+    atomicMin(&g_parse_prof[13], k1 - k0);
+    atomicMax(&g_parse_prof[14], k1 - k0);
+    atomicAdd(&g_parse_prof[15], k1 - k0);
+    if (sub < 8192u) {
+      g_parse_wave[3 * sub] = k0;
+      g_parse_wave[3 * sub + 1] = k1;
+      g_parse_wave[3 * sub + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+    }
+  }
+#endif
 
   // encodeBinTrm(1) closes the substream (cabac_writer.cpp:104-107); decodeBinTrm, arith_codec.cpp:181-197
   uint32_t trm = 1;
@@ -718,9 +769,13 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
 }
 
 #ifdef CABAC_PARSE_PROFILE
+hipError_t debug_read_parse_waves(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_parse_wave), sizeof(unsigned long long) * 3 * 8192);
+}
 hipError_t debug_read_parse_prof(unsigned long long *out) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_parse_prof), sizeof(unsigned long long) * 16);
   unsigned long long zero[16] = {};
+  zero[13] = ~0ull;
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_parse_prof), zero, sizeof zero);
   return e;
 }

@@ -24,4 +24,33 @@ launches = 2.0
 print("parse kernel %.3f ms; per launch, wave 0 (memtime ticks = 100 MHz?):" % r["parse"]["kernel_ms"])
 for k, n in enumerate(names):
     print("  %-14s %12.0f ticks  %5.1f %%" % (n, v[k] / launches, 100.0 * v[k] / max(v[8], 1)))
+print("  wave walk time: min %d  max %d  mean %.0f ticks (2 launches pooled)" % (v[13], v[14], v[15] / (2 * 4096)))
 print("  positions in pass 1: %d, coded groups: %d, blocks: %d (per launch)" % (v[10] / launches, v[11] / launches, v[12] / launches))
+
+w = (ctypes.c_ulonglong * (3 * 8192))()
+L.cabac_hip_debug_parse_waves(w)
+w = np.array(list(w), np.uint64).reshape(-1, 3)[:4096]
+t0 = w[:, 0].min()
+start, end, hw = (w[:, 0] - t0).astype(np.int64), (w[:, 1] - t0).astype(np.int64), w[:, 2]
+dur = end - start
+hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
+xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xf
+# HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
+simd, cu, sh, se = (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 12) & 1, (hwid >> 13) & 7
+print("start spread %d, end max %d" % (start.max(), end.max()))
+key_cu = xcc * 1000 + se * 100 + sh * 16 + cu
+ucu, cnt = np.unique(key_cu, return_counts=True)
+print("distinct CUs %d, waves per CU: min %d max %d" % (len(ucu), cnt.min(), cnt.max()), np.bincount(cnt))
+key_simd = key_cu * 4 + simd
+us, cs = np.unique(key_simd, return_counts=True)
+print("distinct SIMDs %d, waves per SIMD histogram" % len(us), np.bincount(cs))
+per = {}
+for k, c in zip(us, cs):
+    per.setdefault(int(c), []).append(dur[key_simd == k].mean())
+for c in sorted(per):
+    print("  SIMDs with %d waves: mean wave time %.0f" % (c, np.mean(per[c])))
+for c in sorted(set(cnt)):
+    sel = np.isin(key_cu, ucu[cnt == c])
+    print("  CUs with %d waves: mean wave time %.0f" % (c, dur[sel].mean()))
+for x in range(8):
+    print("  xcc %d: waves %d mean %.0f" % (x, (xcc == x).sum(), dur[xcc == x].mean() if (xcc == x).any() else 0))
