@@ -56,11 +56,13 @@ def build_library(force=False, verbose=False):
         if os.path.exists(LIB):
             return LIB  # e.g. a box without the toolchain: use the prebuilt in-tree library
         raise RuntimeError("hipcc not found and no prebuilt libcabac_hip.so")
-    os.makedirs(OBJ, exist_ok=True)
+    import hashlib
+    obj_dir = OBJ + "-" + hashlib.md5(" ".join(FLAGS).encode()).hexdigest()[:8]   # objects of another flag set are not reused
+    os.makedirs(obj_dir, exist_ok=True)
     newest_header = max([os.path.getmtime(p) for p in _headers()] + [os.path.getmtime(__file__)])
     jobs = []
     for src in _sources():
-        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
@@ -71,7 +73,7 @@ def build_library(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, os.path.basename(s) + ".o") for s in _sources()]
+    objs = [os.path.join(obj_dir, os.path.basename(s) + ".o") for s in _sources()]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
     return LIB

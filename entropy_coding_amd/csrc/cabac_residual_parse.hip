@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "cabac_device.h"
 #include "cabac_hip.h"
 #include "cabac_kernels.h"
@@ -374,9 +376,10 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *
     {
       const uint32_t at = (y << g.lwe) + x;
       const bool x1 = x + 1u < g.we, x2 = x + 2u < g.we, y1 = y + 1u < g.he, y2 = y + 2u < g.he;
-      auto mag = [&](bool in, uint32_t idx) {
-        const int32_t v = blk[in ? idx : 0u];
-        return in ? (uint32_t)(v < 0 ? -v : v) : 0u;
+      auto mag = [&](bool in, uint32_t idx) {  // unconditional read from a clamped address: no exec region per sample
+        const uint32_t m = in ? ~0u : 0u;
+        const int32_t v = blk[idx & m];
+        return (uint32_t)(v < 0 ? -v : v) & m;
       };
       const uint32_t a0 = mag(x1, at + 1u), a1 = mag(x2, at + 2u), a2 = mag(x1 && y1, at + pitch + 1u), a3 = mag(y1, at + pitch),
                      a4 = mag(y2, at + 2u * pitch);
@@ -394,8 +397,7 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *
     // and the offset of its gt1 / parity / gt2 contexts — the serial walk reads them with one v_readlane each
     auto sig_slots = [&]() {
       const uint32_t o = min((sc + 1u) >> 1, 3u) + sig_cls;
-      const uint32_t o2 = o | (o << 8);
-      return sig_bases + (o2 | (o2 << 16));
+      return sig_bases + __builtin_amdgcn_perm(o, o, 0u);  // the offset in all four bytes
     };
     uint32_t sig4 = sig_slots(), aofs_v = min(dd, 4u) + abs_cls1;
     const bool is_last_cg = cg == (int32_t)last_cg;
@@ -408,18 +410,18 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *
     // The first position of the group's walk is special (the last significant position of the block: significant by
     // definition, context offset 0) and so is its last (significance inferred when nothing before it was significant and
     // the group flag was coded): both are peeled off the loop's common path by `special`.
-    const int32_t infer_i = is_last_cg ? (int32_t)last_i : (cg != 0 ? 0 : -1);
-    while (i >= 0 && budget >= 4) {
+    // kInfer: the significance of this position is not coded if nothing before it in the group was significant
+    // (:3011-3013); kLast: the block's last significant position — significant by definition, context offset 0.
+    auto position = [&](auto infer, auto at_last) {
       pd_check(d);
       uint32_t sf = 1u;
-      const bool special = i == infer_i;
-      if (!(special && nz_mask == 0u)) {
+      if (!(infer.value && nz_mask == 0u)) {
         sf = pd_bin(d, ctx, (rl(sig4, (uint32_t)i) >> sq) & 0xffu);
         budget--;
       }
       uint32_t par2 = 0;  // 2 * parity of the level
       if (sf) {
-        const uint32_t aofs = (is_last_cg && i == (int32_t)last_i) ? 0u : rl(aofs_v, (uint32_t)i);
+        const uint32_t aofs = at_last.value ? 0u : rl(aofs_v, (uint32_t)i);
         uint32_t level = 1u;
         budget--;
         if (pd_bin(d, ctx, gt1_base + aofs)) {
@@ -442,6 +444,16 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *
       }
       sq = (uint32_t)(trans8 >> (2u * sq + 4u * par2)) & 0xffu;
       i--;
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    if (is_last_cg) {
+      if (budget >= 4) position(yes_t(), yes_t());  // the last significant position itself
+      while (i >= 0 && budget >= 4) position(no_t(), no_t());
+    } else {
+      const int32_t stop = cg != 0 ? 1 : 0;          // position 0 of a group other than the DC group may be inferred
+      while (i >= stop && budget >= 4) position(no_t(), no_t());
+      if (i == 0 && budget >= 4) position(yes_t(), no_t());
     }
     const int32_t bypass_i = i;  // positions bypass_i .. 0 are coded without contexts
     PP_TICK(c3);
