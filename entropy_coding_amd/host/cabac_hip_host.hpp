@@ -225,6 +225,7 @@ public:
     std::function<void(const uint8_t *bytes, uint32_t whole, uint32_t tail_bits)> deliver;
   };
   void submit(Pending &&p) { m_pending.push_back(std::move(p)); }
+  const std::vector<Pending> &pendingSubstreams() const { return m_pending; }  // finished, not yet coded (flush() codes them)
 
 private:
   friend class BinEncoderHip;

@@ -19,6 +19,9 @@
 
 #define private public
 #define protected public
+#define class struct  // Logger's stream is an implicitly private member (log.hpp:131-132); adapter_log_mark() flushes it
+#include "log.hpp"
+#undef class
 #include "cabac_writer.hpp"
 #undef private
 #undef protected
@@ -185,6 +188,80 @@ long adapter_residual(int which, int n, const int *wh, const int *comp, int rig_
     if ((long)f.size() > cap) { strcpy(g_err, "capacity"); return -3; }
     if (!f.empty()) memcpy(out, f.data(), f.size());
     return (long)f.size();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// ---- a syntax walk with its bin_log.txt ---------------------------------------------------------
+// The reference's own CABACWriter walks n_sub substreams; an item of a substream is one coding unit's worth of syntax
+// that needs nothing but the rig: mvd_coding (cabac_writer.cpp:2152-2210), cu_qp_delta (:2356-2379), cu_chroma_qp_offset
+// (:2381-2400) and residual_coding of one transform block (:2424-2525), each of which writes its bin_log.txt lines through
+// binLogger (log.hpp:131-168) before its bins; a substream ends with end_of_slice() (:104-107) and VTM's
+// writeByteAlignment().  which = 0: on the reference's BinEncoder_Std; 1: on BinEncoderHipRef, all substreams coded by one
+// HipBatch::flush() on the device; 2: on BinEncoderHipRef, recording only (no device) — rec / rec_off receive the bin
+// records of every substream.  items: 8 ints each {width, height, comp, rig flags, mvd hor, mvd ver, pred QP, CU QP}.
+// When this file is built against the reference compiled with ENABLE_LOGGING, adapter_log_mark() flushes bin_log.txt
+// (created in the working directory the library was loaded in) and returns its length so far.
+long adapter_log_mark() {
+  binLogger.fs.flush();
+  return (long)binLogger.fs.tellp();
+}
+
+long adapter_walk(int which, int n_sub, const int *sub_first, const int *qp, const int32_t *items, const int32_t *coeff,
+                  uint8_t *out, long cap, long *out_off, uint32_t *nbits, uint16_t *rec, long rec_cap, long *rec_off) {
+  try {
+    static ResidualRig rig;
+    EntropyCodingAMD::HipBatch batch(0);
+    std::vector<OutputBitstream> bs(n_sub);
+    std::vector<std::unique_ptr<BinEncIf>> encs;
+    std::vector<long> coeff_at(size_t(sub_first[n_sub]) + 1, 0);
+    for (int i = 0; i < sub_first[n_sub]; i++) coeff_at[i + 1] = coeff_at[i] + long(items[8 * i]) * items[8 * i + 1];
+    for (int s = 0; s < n_sub; s++) {
+      if (which == 0) encs.emplace_back(new BinEncoder_Std);
+      else encs.emplace_back(new EntropyCodingAMD::BinEncoderHipRef(batch));
+      BinEncIf &enc = *encs.back();
+      CABACWriter w(enc);
+      w.initBitstream(&bs[s]);
+      enc.reset(qp[s], 2);
+      CUCtx cuCtx(0);
+      for (int i = sub_first[s]; i < sub_first[s + 1]; i++) {
+        const int32_t *it = items + 8 * i;
+        w.mvd_coding(Mv(it[4], it[5]), 0);
+        w.cu_qp_delta(*rig.cu, it[6], int8_t(it[7]));
+        w.cu_chroma_qp_offset(*rig.cu);
+        std::vector<TCoeff> buf;
+        TransformUnit tu;
+        rig.make_tu(tu, buf, it[0], it[1], it[2], it[3], coeff + coeff_at[i]);
+        w.residual_coding(tu, ComponentID(it[2]), &cuCtx);
+      }
+      w.end_of_slice();
+    }
+    if (which == 2) {
+      const auto &pend = batch.pendingSubstreams();
+      long at = 0;
+      for (int s = 0; s < n_sub; s++) {
+        rec_off[s] = at;
+        const auto &r = pend[s].records;
+        if (at + (long)r.size() > rec_cap) return -3;
+        if (!r.empty()) memcpy(rec + at, r.data(), r.size() * 2);
+        at += (long)r.size();
+      }
+      rec_off[n_sub] = at;
+      return 0;
+    }
+    if (which == 1) batch.flush();
+    long at = 0;
+    for (int s = 0; s < n_sub; s++) {
+      bs[s].writeByteAlignment();
+      out_off[s] = at;
+      const long n = dump(bs[s], out + at, cap - at, &nbits[s]);
+      if (n < 0) return -3;
+      at += n;
+    }
+    out_off[n_sub] = at;
+    return 0;
   } catch (std::exception &ex) {
     strncpy(g_err, ex.what(), sizeof(g_err) - 1);
     return -1;

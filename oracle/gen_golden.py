@@ -260,6 +260,20 @@ def residual_parse(ref):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def bin_log_walk():
+    """(h) tests/golden/bin_log_walk.json: md5 of the bin_log.txt segment and of the bytes of tests/bin_log_walk.py's walk
+    on the reference built with ENABLE_LOGGING (its own CABACWriter on its own BinEncoder_Std)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="gold_"), "walk.json")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "bin_log_walk.py"), "cpu", out])
+    r = json.load(open(out))["std"]
+    path = os.path.join(GOLD, "bin_log_walk.json")
+    json.dump({"generator": "tests/bin_log_walk.py build_walk() on the reference built with ENABLE_LOGGING (oracle/Makefile)",
+               "log_md5": r["log_md5"], "log_bytes": r["log_bytes"], "stream_md5": r["stream_md5"]}, open(path, "w"), indent=1)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "residual":
         residual(H.load_ref())
@@ -268,3 +282,4 @@ if __name__ == "__main__":
         main()
         residual(H.load_ref())
         residual_parse(H.load_ref())
+        bin_log_walk()
