@@ -270,5 +270,201 @@ private:
   std::vector<Item> m_items;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Decoder side.
+//
+// BinDecoderHipRef IS-A EntropyCoding::BinDecoderBase (reference arith_codec.hpp:215-260) for the supplied-ctxId mode of
+// the device decoder: the ctxId / bypass / terminate sequence of a substream is planned (plan*), decoded by one launch
+// (run), and served back through the decoder's calls, which check that the caller follows the plan.  Of the reference's
+// decoder interface only decodeBin is virtual (arith_codec.hpp:241); decodeBinEP / decodeBinsEP / decodeRemAbsEP /
+// decodeBinTrm / finish are not, so a caller that holds a `BinDecoderBase &` — the reference's CABACReader does,
+// cabac_reader.hpp:142 — reaches this class's versions of them only when those five members are declared virtual in
+// arith_codec.hpp (a five-keyword change); through a `BinDecoderHipRef &` every call is served.
+class BinDecoderHipRef : public EntropyCoding::BinDecoderBase {
+public:
+  explicit BinDecoderHipRef(HipBatch &batch)
+      : EntropyCoding::BinDecoderBase(static_cast<const Common::BinProbModel_Std *>(nullptr)), m_batch(batch) {}
+
+  void reset(int qp, int initId) {  // arith_codec.cpp:75-78
+    Common::Ctx::init(qp, initId);
+    m_qp = qp;
+    m_initId = initId;
+    m_plan.clear();
+    m_bins.clear();
+    m_pos = 0;
+  }
+  void planBin(unsigned ctxId) { m_plan.push_back(uint16_t(ctxId)); }
+  void planBinEP(unsigned n = 1) { m_plan.insert(m_plan.end(), n, uint16_t(CABAC_REC_EP)); }
+  void planBinTrm() { m_plan.push_back(uint16_t(CABAC_REC_TRM)); }
+  void planRecords(const uint16_t *rec, size_t n) { m_plan.insert(m_plan.end(), rec, rec + n); }
+
+  // decode the plan from the bitstream handed to init() (from its current byte position); checkFinish: the stop
+  // pattern check of finish() (arith_codec.cpp:68-73).  Afterwards the bitstream stands where the reference's decoder
+  // would leave it.
+  void run(bool checkFinish) {
+    HIPREF_CHECK(!m_Bitstream, "run(): no bitstream");
+    const std::vector<uint8_t> &fifo = m_Bitstream->getFifo();
+    const uint32_t at = m_Bitstream->getByteLocation();
+    HipBatch::DecodeJob job;
+    job.records = m_plan.data();
+    job.n_records = uint32_t(m_plan.size());
+    job.bytes = fifo.data() + at;
+    job.n_bytes = uint32_t(fifo.size()) - at;
+    job.qp = m_qp;
+    job.initId = m_initId;
+    job.finish = checkFinish;
+    std::vector<std::vector<uint8_t>> bins;
+    std::vector<uint32_t> bitsRead;
+    try {
+      m_batch.decode({job}, bins, &bitsRead);
+    } catch (const EntropyCodingAMD::Exception &e) {
+      HIPREF_THROW(e.what());
+    }
+    m_bins.swap(bins[0]);
+    m_bitsRead = bitsRead[0];
+    m_Bitstream->m_fifo_idx += (m_bitsRead + 8) / 8;  // bytes the reference decoder would have consumed
+    m_pos = 0;
+  }
+
+  unsigned decodeBin(unsigned ctxId) override { return next(ctxId); }  // arith_codec.cpp:242-277
+  unsigned decodeBinEP() { return next(CABAC_REC_EP); }                // :100-114
+  unsigned decodeBinTrm() { return next(CABAC_REC_TRM); }              // :181-197
+  unsigned decodeBinsEP(unsigned numBins) {                            // :116-151
+    unsigned bins = 0;
+    for (unsigned i = 0; i < numBins; i++) bins = (bins << 1) | next(CABAC_REC_EP);
+    return bins;
+  }
+  unsigned decodeRemAbsEP(unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) {  // :153-179
+    const unsigned maxPrefix = 32u - unsigned(maxLog2TrDynamicRange);
+    unsigned prefix = 0;
+    while (prefix < maxPrefix && decodeBinEP()) prefix++;
+    if (prefix < cutoff) return (prefix << goRicePar) + decodeBinsEP(goRicePar);
+    const unsigned offset = ((1u << (prefix - cutoff)) + cutoff - 1u) << goRicePar;
+    return offset + decodeBinsEP(prefix == maxPrefix ? unsigned(maxLog2TrDynamicRange) : goRicePar + prefix - cutoff);
+  }
+  void finish() {}  // the stop pattern was checked on the device (run(true))
+  unsigned getNumBitsRead() const { return m_bitsRead; }
+
+private:
+  unsigned next(unsigned id) {
+    HIPREF_CHECK(m_pos >= m_plan.size(), "decode call beyond the planned sequence");
+    HIPREF_CHECK((m_plan[m_pos] & CABAC_REC_ID_MASK) != id, "decode call does not match the planned ctxId sequence");
+    return m_bins[m_pos++];
+  }
+  HipBatch &m_batch;
+  std::vector<uint16_t> m_plan;
+  std::vector<uint8_t> m_bins;
+  size_t m_pos = 0;
+  int m_qp = 0, m_initId = 0;
+  uint32_t m_bitsRead = 0;
+};
+
+// CABACReader::residual_coding (cabac_reader.cpp:2647-2735, with ts_flag :2737-2752 and residual_codingTS :3130-3339)
+// with the parsing done on the GPU: `residual_coding(tu, compID, cuCtx)` has the reader's signature and queues the block —
+// its geometry and where its coefficients go; endSubstream() has every queued block of the substream parsed by one launch
+// (the contexts are derived on the device from the coefficients decoded so far), writes the coefficients into the
+// TransformUnits' buffers, sets mtsIdx as ts_flag does, updates the CUCtx arguments exactly as the reader does, checks the
+// terminate bin and the stop pattern (end_of_slice / finish) and moves the bitstream on.  The device decoder cannot stop
+// in the middle of a substream and hand over to the host, so this binds where a substream (or the residual partition of
+// one) holds nothing but residual blocks whose sizes are known before their coefficients; INTEGRATION.md section 6.
+// Not covered (throws): SBT zero-out, the range extensions, TS residual coding disabled by the slice.
+class ResidualParserHipRef {
+public:
+  explicit ResidualParserHipRef(HipBatch &batch) : m_batch(batch) {}
+
+  // CABACReader::initBitstream + the decoder's reset(qp, initId): the substream starts at the bitstream's position
+  void beginSubstream(Common::InputBitstream *bitstream, int qp, int initId) {
+    m_Bitstream = bitstream;
+    m_qp = qp;
+    m_initId = initId;
+    m_items.clear();
+  }
+
+  void residual_coding(Common::TransformUnit &tu, Common::ComponentID compID, Common::CUCtx &cuCtx) {
+    using namespace Common;
+    if (compID == COMPONENT_Cr && tu.jointCbCr == 3) return;  // cabac_reader.cpp:2651-2653
+    const SPS &sps = *tu.cs->sps;
+    HIPREF_CHECK(sps.getSpsRangeExtension().getRrcRiceExtensionEnableFlag() ||
+                     sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag() ||
+                     sps.getSpsRangeExtension().getTSRCRicePresentFlag(),
+                 "range-extension Rice derivation is not covered by the GPU parser");
+    HIPREF_CHECK(sps.getUseMTS() && tu.cu->sbtInfo != 0, "SBT zero-out is not covered by the GPU parser");
+    HIPREF_CHECK(tu.cs->slice->getTSResidualCodingDisabledFlag(), "slice_ts_residual_coding_disabled_flag is not covered by the GPU parser");
+    Item it;
+    it.tu = &tu;
+    it.compID = compID;
+    it.cuCtx = &cuCtx;
+    it.b.coeff = nullptr;
+    it.b.width = tu.blocks[compID].width;
+    it.b.height = tu.blocks[compID].height;
+    it.b.chroma = !isLuma(compID);
+    it.b.depQuant = tu.cs->slice->getDepQuantEnabledFlag();
+    it.b.signHiding = tu.cs->slice->getSignDataHidingEnabledFlag();
+    // ts_flag (cabac_reader.cpp:2737-2752): in the stream where transform skip is allowed, otherwise inferred
+    it.b.bdpcm = (isLuma(compID) ? tu.cu->bdpcmMode : tu.cu->bdpcmModeChroma) != 0;
+    it.b.tsFlag = TU::isTSAllowed(tu, compID);
+    it.b.transformSkip = it.b.bdpcm || tu.mtsIdx[compID] == MTS_SKIP;
+    it.b.maxLog2TrDynamicRange = sps.getMaxLog2TrDynamicRange(toChannelType(compID));
+    m_items.push_back(it);
+  }
+
+  // terminate: the substream ends with end_of_slice()'s terminate bin and the stop pattern, which are checked
+  void endSubstream() {
+    using namespace Common;
+    HIPREF_CHECK(!m_Bitstream, "endSubstream(): no bitstream");
+    const std::vector<uint8_t> &fifo = m_Bitstream->getFifo();
+    const uint32_t at = m_Bitstream->getByteLocation();
+    HipBatch::ParseJob job;
+    job.bytes = fifo.data() + at;
+    job.n_bytes = uint32_t(fifo.size()) - at;
+    job.qp = m_qp;
+    job.initId = m_initId;
+    for (const Item &it : m_items) job.blocks.push_back(it.b);
+    std::vector<std::vector<int32_t>> coeff;
+    std::vector<uint32_t> info;
+    try {
+      coeff = m_batch.residualParse({job}, &info);
+    } catch (const EntropyCodingAMD::Exception &e) {
+      m_items.clear();
+      HIPREF_THROW(e.what());
+    }
+    m_Bitstream->m_fifo_idx = uint32_t(fifo.size());  // a substream is consumed whole (its length is what delimited it)
+    const int32_t *c = coeff[0].data();
+    for (size_t t = 0; t < m_items.size(); t++) {
+      const Item &it = m_items[t];
+      const unsigned w = it.b.width, h = it.b.height;
+      TCoeff *dst = it.tu->getCoeffs(it.compID).buf;
+      for (size_t k = 0; k < size_t(w) * h; k++) dst[k] = TCoeff(c[k]);
+      c += size_t(w) * h;
+      const bool ts = (info[t] & CABAC_TU_INFO_TS) != 0;
+      it.tu->mtsIdx[it.compID] = ts ? MTS_SKIP : MTS_DCT2_DCT2;  // ts_flag, :2751
+      if (ts) continue;                                           // residual_codingTS touches no CUCtx
+      CUCtx &cu = *it.cuCtx;                                      // :2668-2693, :2729-2732
+      const int last = int(info[t] & CABAC_TU_INFO_LAST_MASK);
+      const ChannelType ch = it.b.chroma ? CHANNEL_TYPE_CHROMA : CHANNEL_TYPE_LUMA;
+      if (h >= 4 && w >= 4) {
+        const int maxLfnstPos = ((h == 4 && w == 4) || (h == 8 && w == 8)) ? 7 : 15;
+        cu.violatesLfnstConstrained[ch] |= last > maxLfnstPos;
+        cu.lfnstLastScanPos |= last >= (it.b.chroma ? LFNST_LAST_SIG_CHROMA : LFNST_LAST_SIG_LUMA);
+      }
+      if (!it.b.chroma) cu.mtsLastScanPos |= last >= 1;
+      if (!it.b.chroma && (info[t] & CABAC_TU_INFO_MTS_VIOLATION)) cu.violatesMtsCoeffConstraint = true;
+    }
+    m_items.clear();
+  }
+
+private:
+  struct Item {
+    Common::TransformUnit *tu = nullptr;
+    Common::ComponentID compID = Common::COMPONENT_Y;
+    Common::CUCtx *cuCtx = nullptr;
+    HipBatch::ResidualBlock b;
+  };
+  HipBatch &m_batch;
+  Common::InputBitstream *m_Bitstream = nullptr;
+  int m_qp = 0, m_initId = 0;
+  std::vector<Item> m_items;
+};
+
 }  // namespace EntropyCodingAMD
 #endif

@@ -19,6 +19,7 @@
 
 #define private public
 #define protected public
+#include "cabac_reader.hpp"
 #define class struct  // Logger's stream is an implicitly private member (log.hpp:131-132); adapter_log_mark() flushes it
 #include "log.hpp"
 #undef class
@@ -188,6 +189,101 @@ long adapter_residual(int which, int n, const int *wh, const int *comp, int rig_
     if ((long)f.size() > cap) { strcpy(g_err, "capacity"); return -3; }
     if (!f.empty()) memcpy(out, f.data(), f.size());
     return (long)f.size();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// ---- decoder side -----------------------------------------------------------------------------------------------------
+// n residual blocks of one substream, parsed (which = 0) by the reference's own CABACReader::residual_coding on
+// BinDecoder_Std, (which = 1) by ResidualParserHipRef on the device.  block_flags: rig flags per block
+// (oracle/ref_rig.hpp).  coeff_out: the TransformUnits' coefficient buffers afterwards; tu_out[i] = mtsIdx of block i;
+// cu[0..3] = one CUCtx shared by all blocks, as a reader's walk over a coding unit shares it.
+long adapter_residual_parse(int which, int n, const int *wh, const int *comp, const int *block_flags, const uint8_t *in,
+                            long n_in, int qp, int32_t *coeff_out, int32_t *tu_out, int32_t *cu) {
+  try {
+    static ResidualRig rig;
+    InputBitstream ib;
+    ib.getFifo().assign(in, in + n_in);
+    CUCtx cuCtx(0);
+    std::vector<std::unique_ptr<TransformUnit>> tus;
+    std::vector<std::vector<TCoeff>> bufs(n);
+    EntropyCodingAMD::HipBatch batch(0);
+    BinDecoder_Std dec;
+    CABACReader r(dec);
+    EntropyCodingAMD::ResidualParserHipRef hip(batch);
+    // The rig's slice / SPS / CU are shared objects that make_tu sets per block, and both parsers read them while they
+    // parse (the reader at once, the GPU parser's queue call at once too): every block is made right before its call.
+    if (which == 0) {
+      r.initBitstream(&ib);
+      dec.reset(qp, 2);
+    } else {
+      hip.beginSubstream(&ib, qp, 2);
+    }
+    for (int i = 0; i < n; i++) {
+      const int w = wh[2 * i], h = wh[2 * i + 1];
+      std::vector<int32_t> zeros((size_t)w * h, 0);
+      tus.emplace_back(new TransformUnit);
+      rig.make_tu(*tus[i], bufs[i], w, h, comp[i], block_flags[i], zeros.data());
+      if (which == 0) r.residual_coding(*tus[i], ComponentID(comp[i]), cuCtx);
+      else hip.residual_coding(*tus[i], ComponentID(comp[i]), cuCtx);
+    }
+    if (which == 0) {
+      if (dec.decodeBinTrm() != 1) { strcpy(g_err, "terminate bin is not 1"); return -5; }
+      dec.finish();
+    } else {
+      hip.endSubstream();
+    }
+    int32_t *out = coeff_out;
+    for (int i = 0; i < n; i++) {
+      for (size_t k = 0; k < bufs[i].size(); k++) out[k] = (int32_t)bufs[i][k];
+      out += bufs[i].size();
+      tu_out[i] = tus[i]->mtsIdx[comp[i]];
+    }
+    cu[0] = int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_LUMA]) | int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_CHROMA]) << 1;
+    cu[1] = cuCtx.lfnstLastScanPos;
+    cu[2] = cuCtx.violatesMtsCoeffConstraint;
+    cu[3] = cuCtx.mtsLastScanPos;
+    return (long)ib.getByteLocation();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
+// The supplied-ctxId decoder behind the reference's BinDecoderBase: a record stream is planned, run on the device and
+// served — the context bins through a `BinDecoderBase &` (decodeBin is the interface's one virtual), bypass / terminate
+// bins through the class itself.  which = 0 decodes the same with BinDecoder_Std for comparison.
+long adapter_decode_replay(int which, const uint16_t *rec, long n, int qp, int initId, const uint8_t *in, long n_in,
+                           uint8_t *bins, uint32_t *fifo_idx_after) {
+  try {
+    InputBitstream ib;
+    ib.getFifo().assign(in, in + n_in);
+    if (which == 0) {
+      BinDecoder_Std dec;
+      dec.init(&ib);
+      dec.reset(qp, initId);
+      for (long i = 0; i < n; i++) {
+        const unsigned id = rec[i] & CABAC_REC_ID_MASK;
+        bins[i] = uint8_t(id < CABAC_NUM_CONTEXTS ? dec.decodeBin(id) : id == CABAC_REC_EP ? dec.decodeBinEP() : dec.decodeBinTrm());
+      }
+      dec.finish();
+    } else {
+      EntropyCodingAMD::HipBatch batch(0);
+      EntropyCodingAMD::BinDecoderHipRef dec(batch);
+      BinDecoderBase &base = dec;
+      base.init(&ib);
+      dec.reset(qp, initId);
+      dec.planRecords(rec, size_t(n));
+      dec.run(true);
+      for (long i = 0; i < n; i++) {
+        const unsigned id = rec[i] & CABAC_REC_ID_MASK;
+        bins[i] = uint8_t(id < CABAC_NUM_CONTEXTS ? base.decodeBin(id) : id == CABAC_REC_EP ? dec.decodeBinEP() : dec.decodeBinTrm());
+      }
+    }
+    *fifo_idx_after = ib.getByteLocation();
+    return 0;
   } catch (std::exception &ex) {
     strncpy(g_err, ex.what(), sizeof(g_err) - 1);
     return -1;

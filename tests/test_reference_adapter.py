@@ -161,3 +161,83 @@ def test_residual_adapter_empty_block_throws_like_the_reference(adp):
                                  z[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, H._ptr(out, H.u8p), len(out),
                                  cu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
         assert n == -1 and b"empty TU" in adp.adapter_last_error()
+
+
+# ---- decoder side: ResidualParserHipRef / BinDecoderHipRef behind the reference's reader-side types ----------------------
+def _parse(adp, which, metas, rig, data, qp):
+    n = len(metas)
+    wh = np.array([[w, h] for w, h, _ in metas], np.int32).ravel()
+    comp = np.array([c for _, _, c in metas], np.int32)
+    rig = np.asarray(rig, np.int32)
+    total = int(sum(w * h for w, h, _ in metas))
+    co = np.full(total, 0x5A5A5A5A, np.int32)
+    tu = np.zeros(n, np.int32)
+    cu = np.zeros(8, np.int32)
+    ip, i32p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int32)
+    f = adp.adapter_residual_parse
+    f.restype = ctypes.c_long
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, ip, H.u8p, ctypes.c_long, ctypes.c_int, i32p, i32p, i32p]
+    data = np.ascontiguousarray(data, np.uint8)
+    rc = f(which, n, wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), rig.ctypes.data_as(ip), H._ptr(data, H.u8p), len(data), qp,
+           co.ctypes.data_as(i32p), tu.ctypes.data_as(i32p), cu.ctypes.data_as(i32p))
+    assert rc >= 0, adp.adapter_last_error()
+    return co, tu, cu[:4].copy(), rc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_residual_parser_adapter_matches_reference_reader(adp, seed):
+    """CABACReader::residual_coding (reference, on BinDecoder_Std) and ResidualParserHipRef (device) over the same bytes —
+    written by the reference's own CABACWriter::residual_coding —: identical TransformUnit coefficients, mtsIdx and CUCtx.
+    Regular blocks, transform_skip_flag coded 0 / 1, transform skip without a flag, BDPCM; dependent quantisation and sign
+    hiding per block."""
+    ref = H.load_ref()
+    rng = np.random.default_rng(0xAD0 + seed)
+    metas, rig, recs = [], [], []
+    for k in range(36):
+        kind = int(rng.integers(0, 5))
+        comp = int(rng.integers(0, 3))
+        slice_fl = int(rng.integers(0, 4))
+        if kind < 2:
+            w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 16), (2, 8)][int(rng.integers(0, 8))]
+            if kind == 1:
+                w, h = min(w, 32), min(h, 32)
+            c = H.random_block(rng, w, h, density=float(rng.choice([0.1, 0.5, 1.0])), big=float(rng.choice([0.0, 0.2])))
+            fl = slice_fl | (H.TU_TS_FLAG if kind == 1 else 0)
+        else:
+            w, h = int(rng.choice([2, 4, 8, 16, 32])), int(rng.choice([2, 4, 8, 16, 32]))
+            c = ((rng.random((h, w)) < 0.6) * rng.integers(-30, 31, (h, w))).astype(np.int32)
+            if not c.any():
+                c[0, 0] = -2
+            fl = (slice_fl & 1) | H.TU_TRANSFORM_SKIP | [H.TU_TS_FLAG, 0, H.TU_BDPCM][kind - 2]
+        metas.append((w, h, comp))
+        rig.append((fl & 3) | (4 if fl & H.TU_TS_FLAG else 0) | (0x10 if fl & H.TU_TRANSFORM_SKIP else 0) | (0x20 if fl & H.TU_BDPCM else 0))
+        recs.append(ref.residual_records(c, 1 if comp else 0, fl)[0])     # the reference's writer
+    data, _ = ref.encode_records(np.concatenate(recs + [np.array([0x81FF], np.uint16)]), 31, 2, 3)
+    co_r, tu_r, cu_r, pos_r = _parse(adp, 0, metas, rig, data, 31)
+    co_g, tu_g, cu_g, pos_g = _parse(adp, 1, metas, rig, data, 31)
+    assert np.array_equal(co_g, co_r) and np.array_equal(tu_g, tu_r) and np.array_equal(cu_g, cu_r) and pos_g == pos_r
+
+
+@pytest.mark.gpu
+def test_bin_decoder_adapter_serves_the_planned_sequence(adp):
+    """BinDecoderHipRef IS-A BinDecoderBase: the planned ctxId / bypass / terminate sequence decoded on the device comes back
+    through decodeBin (the interface's virtual) and the class's own bypass / terminate calls exactly as BinDecoder_Std
+    decodes it, and the bitstream is left at the same byte."""
+    ref = H.load_ref()
+    rng = np.random.default_rng(77)
+    rec = H.random_records(rng, 6000)
+    data, _ = ref.encode_records(rec, 29, 2, 3)
+    buf = np.concatenate([data, np.array([9, 9, 9], np.uint8)])
+    f = adp.adapter_decode_replay
+    f.restype = ctypes.c_long
+    f.argtypes = [ctypes.c_int, H.u16p, ctypes.c_long, ctypes.c_int, ctypes.c_int, H.u8p, ctypes.c_long, H.u8p, H.u32p]
+    got = {}
+    for which in (0, 1):
+        bins = np.zeros(len(rec), np.uint8)
+        idx = ctypes.c_uint32()
+        rc = f(which, H._ptr(rec, H.u16p), len(rec), 29, 2, H._ptr(buf, H.u8p), len(buf), H._ptr(bins, H.u8p), ctypes.byref(idx))
+        assert rc == 0, adp.adapter_last_error()
+        got[which] = (bins, idx.value)
+    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[0][0], (rec >> 15).astype(np.uint8))
+    assert got[1][1] == got[0][1] == len(data)
