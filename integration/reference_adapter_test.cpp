@@ -26,6 +26,18 @@
 #include "cabac_writer.hpp"
 #undef private
 #undef protected
+
+// BinDecoderBase's only constructor is a member template defined in arith_codec.cpp:50-52; the reference instantiates it
+// implicitly (inlined into TBinDecoder's constructor, no symbol is exported), so a class deriving from BinDecoderBase
+// outside that file cannot link.  A reference tree that adopts BinDecoderHipRef adds one explicit instantiation line to
+// arith_codec.cpp; this test library, which links the unmodified reference, supplies the same
+// constructor as an explicit specialisation instead.
+namespace EntropyCoding {
+template <>
+BinDecoderBase::BinDecoderBase(const Common::BinProbModel_Std *dummy)
+    : Common::Ctx(dummy), m_Bitstream(nullptr), m_Range(0), m_Value(0), m_bitsNeeded(0) {}
+}  // namespace EntropyCoding
+
 #include "reference_adapter.hpp"
 #include "ref_rig.hpp"  // oracle/: test rig around TransformUnit
 
