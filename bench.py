@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: rank 0 holds ONE batch of the workload, LPT-shards it over the ranks "
+                         "(sharding.scatter_substreams over RCCL), every rank codes its shard, the coded bytes are gathered "
+                         "back (BASELINE config 5: --workload C5 --strong)")
     ap.add_argument("--no-residual", action="store_true", help="skip the residual-binariser leg (C4, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
@@ -402,23 +406,50 @@ def main():
             dist.init_process_group(backend)
 
     cfg = CONFIGS[args.workload]
-    n_sub = cfg.n_substreams
-    first = rank * n_sub  # weak scaling: rank r codes substreams [r*n_sub, (r+1)*n_sub) of the same generator
-    desc, records, bytes_total = build_batch(cfg, first=first, count=n_sub)
-    order = build_batch.last_order  # generator index of each descriptor row (LPT order for mixed lengths)
-    n_bins = int(desc["n_records"].astype(np.int64).sum())
-    n_slots = int(len(records))  # records/bins buffers include the stagger gaps (never touched)
-
     stream = torch.cuda.current_stream()
     hip = capi.CabacHip(local_rank, stream=stream.cuda_stream)
     hip.set_variant(args.enc_variant, args.dec_variant)
+    scatter_ms = gather_ms_strong = None
+    if args.strong:
+        # ---- strong scaling: ONE batch on rank 0, sharded over the ranks ------------------------------------------
+        from entropy_coding_amd import sharding
+        whole = None
+        if rank == 0:
+            wdesc, wrec, _ = build_batch(cfg, stagger=False)
+            worder = build_batch.last_order
+            whole = (wdesc, torch.from_numpy(wrec.view(np.int16)).cuda())       # the batch resident on the ingest GPU
+            del wrec
+        if world > 1:
+            barrier_sync = lambda: (torch.cuda.synchronize(), dist.barrier())
+            barrier_sync()
+            t0 = time.perf_counter()
+            desc, rec_u8, bytes_total, my_idx = sharding.scatter_substreams(whole[0] if rank == 0 else None,
+                                                                            whole[1] if rank == 0 else None, root=0)
+            barrier_sync()
+            scatter_ms = (time.perf_counter() - t0) * 1e3
+            t_rec = rec_u8.view(torch.int16) if rec_u8.device.type == "cuda" else rec_u8.view(torch.int16).cuda()
+        else:
+            desc, t_rec, bytes_total = sharding.pack_shard(whole[0], whole[1], np.arange(len(whole[0])))
+            my_idx = np.arange(len(desc), dtype=np.int64)
+        n_sub = len(desc)
+        order = None
+        n_bins = int(desc["n_records"].astype(np.int64).sum())
+        n_slots = int(t_rec.numel())
+        records = None
+    else:
+        n_sub = cfg.n_substreams
+        first = rank * n_sub  # weak scaling: rank r codes substreams [r*n_sub, (r+1)*n_sub) of the same generator
+        desc, records, bytes_total = build_batch(cfg, first=first, count=n_sub)
+        order = build_batch.last_order  # generator index of each descriptor row (LPT order for mixed lengths)
+        n_bins = int(desc["n_records"].astype(np.int64).sum())
+        n_slots = int(len(records))  # records/bins buffers include the stagger gaps (never touched)
+        t_rec = torch.from_numpy(records.view(np.int16)).cuda()
 
     t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
-    t_rec = torch.from_numpy(records.view(np.int16)).cuda()
-    t_bytes = torch.zeros(bytes_total, dtype=torch.uint8, device="cuda")
-    t_res_e = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
-    t_res_d = torch.zeros(n_sub * 2, dtype=torch.int32, device="cuda")
-    t_bins = torch.zeros(n_slots, dtype=torch.uint8, device="cuda")
+    t_bytes = torch.zeros(max(bytes_total, 16), dtype=torch.uint8, device="cuda")
+    t_res_e = torch.zeros(max(n_sub, 1) * 2, dtype=torch.int32, device="cuda")
+    t_res_d = torch.zeros(max(n_sub, 1) * 2, dtype=torch.int32, device="cuda")
+    t_bins = torch.zeros(max(n_slots, 1), dtype=torch.uint8, device="cuda")
 
     def step():
         hip.encode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res_e.data_ptr())
@@ -454,15 +485,45 @@ def main():
     enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
 
     # ---- verification after the timed region: hashes + round trip ------------------------------
-    res_e = t_res_e.cpu().numpy().view(capi.RESULT_DTYPE)
-    res_d = t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)
+    res_e = t_res_e.cpu().numpy().view(capi.RESULT_DTYPE)[:n_sub]
+    res_d = t_res_d.cpu().numpy().view(capi.RESULT_DTYPE)[:n_sub]
     ok = not res_e["flags"].any() and not res_d["flags"].any()
     want_bins = (t_rec < 0).to(torch.uint8)
-    ok = ok and bool(torch.equal(t_bins, want_bins))
+    ok = ok and bool(torch.equal(t_bins[:n_slots], want_bins))
     out_bytes = int(((res_e["n_bits"].astype(np.int64) + 7) // 8).sum())
     hash_match = None
-    if rank == 0:
-        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_md5.json")))[cfg.name]
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_md5.json")))[cfg.name]
+    if args.strong:
+        # every rank compacts its coded substreams on the device; they travel back to rank 0 device to device and are put
+        # in global substream order there: md5s of the reference's bytes (tests/golden/synth_md5.json)
+        from entropy_coding_amd import sharding
+        t_pay = torch.zeros(max(out_bytes, 1), dtype=torch.uint8, device="cuda")
+        t_offs = torch.zeros(n_sub + 1, dtype=torch.int64, device="cuda")
+        hip.assemble_device(n_sub, t_desc.data_ptr(), t_res_e.data_ptr(), t_bytes.data_ptr(), t_pay.data_ptr(), out_bytes, t_offs.data_ptr())
+        hip.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            got = sharding.gather_payloads(my_idx, res_e, t_pay[:out_bytes] if backend == "nccl" else t_pay[:out_bytes].cpu(), root=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gather_ms_strong = (time.perf_counter() - g0) * 1e3
+        else:
+            got = [(my_idx, res_e, t_pay[:out_bytes])]
+        if rank == 0:
+            streams, _ = sharding.ordered_streams(len(whole[0]), got)
+            row_of = {int(idx): k for k, idx in enumerate(worder)}
+            hash_match = all(s is not None for s in streams)
+            cat = hashlib.md5()
+            for g in gold["substreams"]:
+                b = streams[row_of[g["index"]]]
+                hash_match = hash_match and hashlib.md5(b.tobytes()).hexdigest() == g["md5"]
+                cat.update(b.tobytes())
+            hash_match = hash_match and cat.hexdigest() == gold["concat_md5"]
+            total_payload = int(sum(len(s) for s in streams))
+            del streams
+    elif rank == 0:
         host_bytes = t_bytes.cpu().numpy()
         hash_match = True
         row_of = {int(idx): k for k, idx in enumerate(order)}
@@ -513,7 +574,7 @@ def main():
 
     # ---- residual binariser on coefficient blocks, outside the timed region ----------
     residual = None
-    if world == 1 and cfg.name == "C4" and not args.no_residual:
+    if world == 1 and cfg.name == "C4" and not args.no_residual and not args.strong:
         try:
             residual = residual_leg(hip, n_sub)
         except Exception as e:  # the headline line must not depend on this leg
@@ -522,19 +583,25 @@ def main():
     # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
     gather_ms = None
     if world > 1:
-        sizes = t_res_e.view(-1, 2)[:, 0].contiguous().to(coll_dev)
-        allsz = [torch.empty_like(sizes) for _ in range(world)]
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        dist.all_gather(allsz, sizes)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        if not args.strong:
+            sizes = t_res_e.view(-1, 2)[:, 0].contiguous().to(coll_dev)
+            allsz = [torch.empty_like(sizes) for _ in range(world)]
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            dist.all_gather(allsz, sizes)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
         flag = torch.tensor([1 if ok else 0], device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
+    bins_all = n_bins * world
+    if args.strong and world > 1:
+        t = torch.tensor([n_bins], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t)
+        bins_all = int(t.item())
     if rank == 0:
-        total_bins_per_step = 2 * n_bins * world  # N encoded + N decoded, on every rank
+        total_bins_per_step = 2 * bins_all  # N encoded + N decoded over all ranks
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bins_per_step / (elapsed / args.steps) / 1e6
         bytes_enc = 2 * n_bins + out_bytes + (DESC_BYTES + RESULT_BYTES) * n_sub
@@ -554,7 +621,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -565,7 +632,8 @@ def main():
                 "bins_per_gpu": n_bins,
                 "ctx_permille": cfg.substream(0)[1],
                 "bins_per_step": total_bins_per_step,
-                "sharding": "substreams split across ranks, no data-path collective",
+                "sharding": ("one batch on rank 0, LPT-sharded over the ranks (send/recv over RCCL), coded bytes gathered back; no data-path collective"
+                             if args.strong else "substreams split across ranks, no data-path collective"),
                 "kernel_variants": {"encode": args.enc_variant, "decode": args.dec_variant},
             },
             "encode_mbins_s": round(n_bins / (enc_avg * 1e-3) / 1e6, 2),
@@ -601,12 +669,18 @@ def main():
             line["residual"] = residual
         if gather_ms is not None:
             line["sizes_allgather_ms"] = round(gather_ms, 3)
-        if world == 1 and not args.no_end_to_end:
+        if args.strong:
+            line["strong"] = {"substreams_total": int(len(whole[0])), "bins_total": bins_all,
+                              "scatter_ms": None if scatter_ms is None else round(scatter_ms, 3),
+                              "gather_ms": None if gather_ms_strong is None else round(gather_ms_strong, 3),
+                              "scatter_bytes": 2 * bins_all, "gathered_payload_bytes": total_payload,
+                              "what": "scatter / gather are outside the timed region: the step is encode + decode of the resident shard"}
+        if world == 1 and not args.no_end_to_end and not args.strong:
             try:
                 line["end_to_end"] = end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins)
             except Exception as e:  # the headline line must not depend on this leg
                 line["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.strong:
             line["cpu_baseline"] = cpu_baseline(cfg, desc, records, args.cpu_seconds)
         if not line["hash_match"]:
             line["error"] = "bitstream hash / round-trip mismatch"

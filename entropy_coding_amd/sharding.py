@@ -4,10 +4,18 @@ CABAC substreams (slices / tiles / frames) are independent units: private contex
 low/range, private byte stream (reference cabac_writer.cpp:16-39, :104-107); the only cross-unit
 operation is the ordered concatenation of the finished byte strings (bit_stream.cpp:139-150).  So the
 data path has NO collective: each rank codes its own substreams.  torch.distributed (backend "nccl" =
-RCCL over xGMI on the GPU box, "gloo" in CPU tests) is used only for the scatter of the bin records from
-the ingest rank and the gather of the variable-length results, as point-to-point send/recv pairs: on a
-fully connected 8-GPU xGMI node a direct star uses all 7 links of the root concurrently, whereas a ring
-collective would be bound by one link.
+RCCL over xGMI on the GPU box, "gloo" in CPU tests) moves the bin records from the ingest rank to the
+ranks and the coded bytes back:
+
+* payloads stay where the backend wants them — device tensors under RCCL (records are cut out of the
+  root's device buffer and land in the receivers' device buffers; the coded bytes travel back device to
+  device), CPU tensors under gloo;
+* the sizes of everything a transfer will carry are exchanged ONCE, as a collective (broadcast of the
+  root's table for the scatter, all_gather for the gather), not as a message in front of every array;
+* the point-to-point transfers of one scatter (or gather) are posted TOGETHER with
+  dist.batch_isend_irecv and waited for once: on a fully connected 8-GPU xGMI node the root's seven
+  links then carry their transfers at the same time (a ring collective would be bound by one link,
+  blocking sends one after another by the sum).
 """
 import numpy as np
 import torch
@@ -33,95 +41,145 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def _send_array(a, dst):
-    t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(_dev())
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=_dev())
-    dist.send(n, dst)
-    if t.numel():
-        dist.send(t, dst)
+def _as_bytes(a):
+    """numpy array or torch tensor -> flat uint8 tensor on the transport device (a view where it already lives there)."""
+    if isinstance(a, torch.Tensor):
+        return a.contiguous().view(-1).view(torch.uint8).to(_dev())
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(_dev())
 
 
-def _recv_array(src, dtype):
-    n = torch.zeros(1, dtype=torch.int64, device=_dev())
-    dist.recv(n, src)
-    t = torch.empty(int(n.item()), dtype=torch.uint8, device=_dev())
-    if t.numel():
-        dist.recv(t, src)
+def _to_numpy(t, dtype):
     return t.cpu().numpy().view(dtype)
 
 
+# ---- transport ---------------------------------------------------------------------------------------------------
+def star_scatter(parts, n_parts, root=0):
+    """Root holds parts[r] = [tensor-like, ...] (n_parts of them) for every rank r; every rank gets its own list of flat
+    uint8 tensors on the transport device.  One broadcast of the size table, then all transfers in one batch."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    table = torch.zeros(world * n_parts, dtype=torch.int64, device=_dev())
+    if rank == root:
+        parts = [[_as_bytes(p) for p in parts[r]] for r in range(world)]
+        table = torch.tensor([p.numel() for r in range(world) for p in parts[r]], dtype=torch.int64, device=_dev())
+    dist.broadcast(table, root)
+    sizes = table.cpu().numpy().reshape(world, n_parts)
+    ops, mine = [], None
+    if rank == root:
+        mine = parts[root]
+        for r in range(world):
+            if r != root:
+                ops += [dist.P2POp(dist.isend, p, r) for p in parts[r] if p.numel()]
+    else:
+        mine = [torch.empty(int(n), dtype=torch.uint8, device=_dev()) for n in sizes[rank]]
+        ops = [dist.P2POp(dist.irecv, t, root) for t in mine if t.numel()]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return mine
+
+
+def star_gather(my_parts, root=0):
+    """Every rank hands in a list of tensor-likes; root gets [[flat uint8 tensors of rank 0], [of rank 1], ...].
+    One all_gather of the sizes, then all transfers in one batch."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    my_parts = [_as_bytes(p) for p in my_parts]
+    n_parts = len(my_parts)
+    mine = torch.tensor([p.numel() for p in my_parts], dtype=torch.int64, device=_dev())
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    ops, got = [], None
+    if rank == root:
+        got = []
+        for r in range(world):
+            if r == root:
+                got.append(my_parts)
+                continue
+            bufs = [torch.empty(int(n), dtype=torch.uint8, device=_dev()) for n in sizes[r].cpu().numpy()]
+            ops += [dist.P2POp(dist.irecv, t, r) for t in bufs if t.numel()]
+            got.append(bufs)
+    else:
+        ops = [dist.P2POp(dist.isend, p, root) for p in my_parts if p.numel()]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return got
+
+
+# ---- substreams --------------------------------------------------------------------------------------------------
 def pack_shard(desc, records, idxs):
-    """Re-pack the substreams `idxs` of (desc, records) into a self-contained shard."""
+    """Re-pack the substreams `idxs` of (desc, records) into a self-contained shard: (desc, records, bytes_total).
+    `records` may be a numpy array or a torch tensor (e.g. the root's device buffer): the shard's records are of the
+    same kind."""
     sub = desc[idxs].copy()
     lens = sub["n_records"].astype(np.int64)
     caps = sub["byte_capacity"].astype(np.int64)
     sub["rec_offset"] = np.concatenate([[0], np.cumsum(lens)[:-1]]) if len(idxs) else []
     sub["byte_offset"] = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16)[:-1]]) if len(idxs) else []
-    recs = np.concatenate([records[int(desc["rec_offset"][i]):int(desc["rec_offset"][i]) + int(desc["n_records"][i])]
-                           for i in idxs]) if len(idxs) else np.zeros(0, np.uint16)
+    pieces = [records[int(desc["rec_offset"][i]):int(desc["rec_offset"][i]) + int(desc["n_records"][i])] for i in idxs]
+    if isinstance(records, torch.Tensor):
+        recs = torch.cat(pieces) if pieces else records[:0]
+    else:
+        recs = np.concatenate(pieces) if pieces else np.zeros(0, np.uint16)
     return sub, recs, int(((caps + 15) // 16 * 16).sum())
 
 
 def scatter_substreams(desc, records, root=0):
-    """Root holds the whole batch; every rank returns its shard (desc, records, bytes_total, global_idx)."""
+    """Root holds the whole batch (desc: numpy; records: numpy or a torch tensor); every rank returns its shard
+    (desc numpy, records flat uint8 tensor on the transport device — 2 bytes per record —, bytes_total, global indices)."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    mine = None
+    parts = None
     if rank == root:
         owners = lpt_assign(desc["n_records"], world)
+        parts = []
         for r in range(world):
-            d, rec, total = pack_shard(desc, records, owners[r])
-            if r == root:
-                mine = (d, rec, total, np.asarray(owners[r], np.int64))
-            else:
-                _send_array(d, r)
-                _send_array(rec, r)
-                _send_array(np.asarray(owners[r], np.int64), r)
-    else:
-        d = _recv_array(root, capi.DESC_DTYPE).copy()
-        rec = _recv_array(root, np.uint16).copy()
-        idx = _recv_array(root, np.int64).copy()
-        total = int(((d["byte_capacity"].astype(np.int64) + 15) // 16 * 16).sum())
-        mine = (d, rec, total, idx)
-    return mine
+            d, rec, _ = pack_shard(desc, records, owners[r])
+            parts.append([d, rec, np.asarray(owners[r], np.int64)])
+    d, rec, idx = star_scatter(parts, 3, root)
+    d = _to_numpy(d, capi.DESC_DTYPE).copy()
+    total = int(((d["byte_capacity"].astype(np.int64) + 15) // 16 * 16).sum())
+    return d, rec, total, _to_numpy(idx, np.int64).copy()
 
 
-def gather_bitstreams(n_total, idx, desc, out_bytes, results, root=0):
-    """Gather the coded substreams on root in global substream order.
-    Returns on root: (list of per-substream byte arrays, n_bits array); elsewhere None."""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    nbytes = (results["n_bits"].astype(np.int64) + 7) // 8
-    payload = np.concatenate([out_bytes[int(desc["byte_offset"][k]):int(desc["byte_offset"][k]) + int(nbytes[k])]
-                              for k in range(len(desc))]) if len(desc) else np.zeros(0, np.uint8)
-    if rank != root:
-        _send_array(idx, root)
-        _send_array(results, root)
-        _send_array(payload, root)
+def gather_payloads(idx, results, payload, root=0):
+    """Every rank hands in the global indices of its substreams, their results and their coded bytes back to back
+    (numpy or tensor).  Root returns [(idx, results, payload tensor)] per rank; the others None."""
+    got = star_gather([np.asarray(idx, np.int64), results, payload], root)
+    if got is None:
         return None
+    return [(_to_numpy(g[0], np.int64), _to_numpy(g[1], capi.RESULT_DTYPE), g[2]) for g in got]
+
+
+def ordered_streams(n_total, gathered):
+    """(list of per-substream byte arrays in global order, n_bits array) from gather_payloads' result."""
     streams = [None] * n_total
     n_bits = np.zeros(n_total, np.uint32)
-    for r in range(world):
-        if r == root:
-            ridx, rres, rpay = idx, results, payload
-        else:
-            ridx = _recv_array(r, np.int64)
-            rres = _recv_array(r, capi.RESULT_DTYPE)
-            rpay = _recv_array(r, np.uint8)
+    for ridx, rres, rpay in gathered:
+        pay = rpay.cpu().numpy()
         rn = (rres["n_bits"].astype(np.int64) + 7) // 8
         off = np.concatenate([[0], np.cumsum(rn)])
         for k, g in enumerate(ridx):
-            streams[int(g)] = rpay[int(off[k]):int(off[k + 1])].copy()
+            streams[int(g)] = pay[int(off[k]):int(off[k + 1])].copy()
             n_bits[int(g)] = rres["n_bits"][k]
     return streams, n_bits
 
 
+def compact_payload(desc, out_bytes, results):
+    """The coded substreams of a shard back to back (host arrays; on the device cabac_hip_assemble_device does this)."""
+    nbytes = (results["n_bits"].astype(np.int64) + 7) // 8
+    return np.concatenate([out_bytes[int(desc["byte_offset"][k]):int(desc["byte_offset"][k]) + int(nbytes[k])]
+                           for k in range(len(desc))]) if len(desc) else np.zeros(0, np.uint8)
+
+
 def encode_sharded(desc, records, encode_fn, root=0):
     """Scatter -> encode locally with encode_fn(desc, records, bytes_total) -> (bytes, results) -> gather.
-    `encode_fn` is CabacHip.encode_batch on a GPU box; tests inject a CPU checker."""
+    `encode_fn` is CabacHip.encode_batch on a GPU box; tests inject a CPU checker.  Returns on root
+    (list of per-substream byte arrays, n_bits array); elsewhere None."""
     n_total = torch.tensor([len(desc) if dist.get_rank() == root else 0], dtype=torch.int64, device=_dev())
     dist.broadcast(n_total, root)
     d, rec, total, idx = scatter_substreams(desc, records, root)
-    out, res = encode_fn(d, rec, total)
-    return gather_bitstreams(int(n_total.item()), idx, d, out, res, root)
+    out, res = encode_fn(d, _to_numpy(rec, np.uint16), total)
+    got = gather_payloads(idx, res, compact_payload(d, out, res), root)
+    return None if got is None else ordered_streams(int(n_total.item()), got)
 
 
 # ---- residual binariser (SURVEY §8 row f2): transform blocks shard the same way ------------------------------------
@@ -147,38 +205,24 @@ def residual_sharded(tus, coeff, tile_first, residual_fn, root=0):
     rank, world = dist.get_rank(), dist.get_world_size()
     n_total = torch.tensor([len(tus) if rank == root else 0], dtype=torch.int64, device=_dev())
     dist.broadcast(n_total, root)
+    parts = None
     if rank == root:
         sizes = (1 << (tus["log2_width"].astype(np.int64) + tus["log2_height"].astype(np.int64)))
         csum = np.concatenate([[0], np.cumsum(sizes)])
         weight = csum[np.asarray(tile_first[1:], np.int64)] - csum[np.asarray(tile_first[:-1], np.int64)]
         owners = lpt_assign(weight, world)
-        mine = None
-        for r in range(world):
-            shard = pack_tiles(tus, coeff, tile_first, owners[r])
-            if r == root:
-                mine = shard
-            else:
-                for a in shard:
-                    _send_array(a, r)
-    else:
-        mine = (_recv_array(root, capi.TU_DTYPE).copy(), _recv_array(root, np.int32).copy(), _recv_array(root, np.int64).copy())
-    sub, co, blk = mine
+        parts = [list(pack_tiles(tus, coeff, tile_first, owners[r])) for r in range(world)]
+    sub, co, blk = star_scatter(parts, 3, root)
+    sub, co, blk = _to_numpy(sub, capi.TU_DTYPE).copy(), _to_numpy(co, np.int32).copy(), _to_numpy(blk, np.int64).copy()
     rec, off, info = residual_fn(sub, co) if len(sub) else (np.zeros(0, np.uint16), np.zeros(1, np.uint64), np.zeros(0, np.uint32))
-    if rank != root:
-        _send_array(blk, root)
-        _send_array(np.asarray(off, np.uint64), root)
-        _send_array(np.asarray(info, np.uint32), root)
-        _send_array(np.asarray(rec, np.uint16), root)
+    got = star_gather([blk, np.asarray(off, np.uint64), np.asarray(info, np.uint32), np.asarray(rec, np.uint16)], root)
+    if got is None:
         return None
     out = [None] * int(n_total.item())
     infos = np.zeros(int(n_total.item()), np.uint32)
-    for r in range(world):
-        if r == root:
-            rblk, roff, rinfo, rrec = blk, np.asarray(off, np.uint64), np.asarray(info, np.uint32), np.asarray(rec, np.uint16)
-        else:
-            rblk, roff, rinfo, rrec = (_recv_array(r, np.int64), _recv_array(r, np.uint64), _recv_array(r, np.uint32),
-                                       _recv_array(r, np.uint16))
-        for k, g in enumerate(rblk):
-            out[int(g)] = rrec[int(roff[k]): int(roff[k + 1])].copy()
-            infos[int(g)] = rinfo[k]
+    for g in got:
+        rblk, roff, rinfo, rrec = _to_numpy(g[0], np.int64), _to_numpy(g[1], np.uint64), _to_numpy(g[2], np.uint32), _to_numpy(g[3], np.uint16)
+        for k, b in enumerate(rblk):
+            out[int(b)] = rrec[int(roff[k]): int(roff[k + 1])].copy()
+            infos[int(b)] = rinfo[k]
     return out, infos
