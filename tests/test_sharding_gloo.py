@@ -120,3 +120,47 @@ def test_residual_tiles_scatter_binarise_gather(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def _tensor_worker(rank, world, port, q):
+    """records handed over as a torch tensor (the bench's device buffer), fewer substreams than ranks: one shard is empty."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = H.load_oracle()
+    desc = records = None
+    if rank == 0:
+        rng = np.random.default_rng(7)
+        recs = [H.random_records(rng, n - 1) for n in (900, 41)]
+        desc, total = H.make_desc([900, 41], [30, 31], [2, 2], H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+        records = np.concatenate(recs)
+    d, rec, total_r, idx = sharding.scatter_substreams(desc, torch.from_numpy(records.view(np.int16)) if rank == 0 else None, root=0)
+    assert rec.dtype == torch.uint8 and len(d) == len(idx)
+    out, res = orc.encode_batch(d, rec.numpy().view(np.uint16), total_r)
+    got = sharding.gather_payloads(idx, res, torch.from_numpy(sharding.compact_payload(d, out, res)), root=0)
+    if rank == 0:
+        streams, n_bits = sharding.ordered_streams(2, got)
+        want_out, want_res = orc.encode_batch(desc, records, total)
+        ok = sorted(len(g[0]) for g in got) == [0, 1, 1]
+        for s in range(2):
+            o, nb = int(desc["byte_offset"][s]), (int(want_res["n_bits"][s]) + 7) // 8
+            ok = ok and np.array_equal(streams[s], want_out[o:o + nb]) and n_bits[s] == want_res["n_bits"][s]
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_gather_with_tensor_records_and_an_empty_shard():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tensor_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
