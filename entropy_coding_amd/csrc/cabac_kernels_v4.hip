@@ -865,8 +865,9 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   uint8_t *rrate = rate_all + (wave * kQuadSubs + row) * kQuadCtxStride;
-  uint16_t *tag_mine = tag_all + ((wave * kQuadSubs + row) * 2u + (j >> 3)) * kTagStride;         // this lane's half
-  uint16_t *tag_other = tag_all + ((wave * kQuadSubs + row) * 2u + ((j >> 3) ^ 1u)) * kTagStride;  // the other half
+  // (volatile: the read-back right after the write must come from LDS — another lane may have written the slot too)
+  volatile uint16_t *tag_mine = tag_all + ((wave * kQuadSubs + row) * 2u + (j >> 3)) * kTagStride;         // this lane's half
+  volatile uint16_t *tag_other = tag_all + ((wave * kQuadSubs + row) * 2u + ((j >> 3) ^ 1u)) * kTagStride;  // the other half
   const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -992,6 +993,9 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
         // a context of the first half comes again in the second: its update goes through the context store in between
         const uint32_t first_half = neg_mask(j - 8u);  // ~0 in lanes 0..7
         rctx[sel(first_half, commit_slot, (uint32_t)kNumCtx)] = quad_dec_commit(st_v, r0_v, a_v, (bits >> j) & 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the re-read below sees the other lanes' stores
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         st_v = rctx[slot] & ctxm;
         quad_dec_derive(st_v, kq_v, sx_v);
         QFAST(8); QFAST(9); QFAST(10); QFAST(11); QFAST(12); QFAST(13); QFAST(14); QFAST(15);
