@@ -691,7 +691,6 @@ __device__ __forceinline__ void quad_dec_stage_store(QuadDec &w) {
 }
 
 constexpr uint32_t kRingStride = 66;  // 64 ring dwords + the mirror of dword 0 + a dump word
-constexpr uint32_t kTagStride = 400;  // 380 context slots + one private slot per lane for records without a context
 
 // One decode step for the four rows.  Written with bit masks instead of ?: on purpose: on a lone wave
 // every exec-mask region hipcc builds out of a conditional costs a VALU->SALU->EXEC round trip.  The cost
@@ -775,67 +774,6 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   }
 }
 
-// The same step for 16-bin groups (or 8-bin halves) in which no context occurs twice in a row's bins — found out in the
-// step's prologue, see the kernel.  Then no bin of the group changes a state that a later bin of the group reads: every
-// lane derives the LPS factor and the MPS of ITS record's state once, before the group (kq_v = k | MPS mask << 24: the
-// 24-bit multiply ignores the top byte; sx_v = MPS mask), the use site is two row broadcasts instead of a broadcast and
-// four dependent instructions, and the per-bin state update on all lanes (six instructions) becomes ONE update per lane
-// after the group, with the lane's own bin (quad_dec_commit).  23 instructions per bin instead of 33.
-template <int I>
-__device__ __forceinline__ void quad_dec_step_fast(const QuadDecInfo &f, uint32_t kq_v, uint32_t sx_v, uint32_t &bits,
-                                                   QuadDec &w) {
-  uint64_t refill = 0, refill2 = 0;
-  if ((I & 3) == 0) {
-    refill = __ballot(w.look <= 31);
-    refill2 = __ballot(w.look <= 21);
-    asm volatile("" : "+s"(refill), "+s"(refill2));
-  }
-  const uint32_t t = (__umul24(w.range >> 5, row_bcast<I>(kq_v)) + row_bcast<I>(f.c2)) >> 1;
-  const uint32_t rm = w.range - t;
-  const uint32_t sr = __umul24(rm, row_bcast<I>(f.srmul));
-  const uint32_t e = w.hi - sr;
-  uint32_t ngem;
-  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(e));
-  const uint32_t bin = ~(ngem ^ row_bcast<I>(sx_v)) & 1u;
-  const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
-  const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;
-  uint32_t nm;
-  asm("v_bitop3_b32 %0, %1, %2, 1 bitop3:0x20" : "=v"(nm) : "v"(ngem), "v"(rm >> 8));
-  const uint32_t nsh = (gc & nl) | nm;
-  w.hi = sel(ngem, w.hi, e);
-  w.range = sel(gc, t, rm) << nsh;
-  {
-    uint32_t tot;
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(tot) : "v"(f.ep), "v"(nsh), "n"(I));
-    const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
-    w.hi = (uint32_t)(v >> 32);
-    w.lo = (uint32_t)v;
-    w.look -= (int32_t)tot;
-  }
-  bits |= bin << I;
-  if ((I & 3) == 0 && refill != 0) {
-    quad_dec_check(w, refill2 != 0);
-  }
-}
-
-// every lane's LPS factor / MPS from its own state word (contexts.cpp:939-950), for quad_dec_step_fast
-__device__ __forceinline__ void quad_dec_derive(uint32_t st_v, uint32_t &kq_v, uint32_t &sx_v) {
-  const uint32_t sum = (st_v & 0xffffu) + (st_v >> 16);
-  sx_v = (uint32_t)((int32_t)(sum << 16) >> 31);
-  kq_v = (((sum >> 10) ^ sx_v) & 31u) | (sx_v << 24);
-}
-
-// the one update of a group: this lane's state with this lane's bin (update(), contexts.cpp:903-913)
-__device__ __forceinline__ uint32_t quad_dec_commit(uint32_t st_v, uint32_t r0_v, uint32_t a_v, uint32_t my_bin) {
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  const u16x2 st2 = __builtin_bit_cast(u16x2, st_v);
-  const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, r0_v)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
-  const uint32_t rest = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2));
-  uint32_t upd;
-  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(a_v), "v"(my_bin), "v"(rest));
-  return upd;
-}
-
 template <bool kSpecial>
 __device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                                uint32_t &bits, QuadDec &w) {
@@ -859,15 +797,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint8_t rate_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t ring_all[W * kQuadSubs * kRingStride];
-  // which lane of a row's half holds a context in the current step: [row][half][slot], stamped with the step number
-  __shared__ uint16_t tag_all[W * kQuadSubs * 2 * kTagStride];
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   uint8_t *rrate = rate_all + (wave * kQuadSubs + row) * kQuadCtxStride;
-  // (volatile: the read-back right after the write must come from LDS — another lane may have written the slot too)
-  volatile uint16_t *tag_mine = tag_all + ((wave * kQuadSubs + row) * 2u + (j >> 3)) * kTagStride;         // this lane's half
-  volatile uint16_t *tag_other = tag_all + ((wave * kQuadSubs + row) * 2u + ((j >> 3) ^ 1u)) * kTagStride;  // the other half
   const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -963,51 +896,13 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     f.alm = aln_m;
     f.key = sel(ctxm, id, 0x200u + j);
     next_rec = rec_safe[min(base + 16u + j, last_rec)];  // prefetch the next step's records
-    // Does a context occur twice among the bins 0..7 or among the bins 8..15 of a row (same), or in both halves (cross)?
-    // Every lane stamps its context's slot in its half's tag table and reads it back: with two lanes of a half on one
-    // slot one of them finds the other's stamp; the other half's table tells whether that half uses the context too.
-    // (A stale stamp can only make a group look shared — the slower variant — never hide a sharing.)
-    const uint32_t stamp = ((base >> 4) << 4) & 0xfff0u;
-    const uint32_t tslot = sel(ctxm, id, (uint32_t)kNumCtx + 1u + j);
-    tag_mine[tslot] = (uint16_t)(stamp | j);
-    const uint32_t seen_mine = tag_mine[tslot], seen_other = tag_other[tslot];
-    uint64_t dup_same = __ballot((ctxm & (seen_mine ^ (stamp | j))) != 0u);
-    uint64_t dup_cross = __ballot((ctxm & neg_mask(((seen_other ^ stamp) & 0xffffu) - 16u)) != 0u);
-    asm volatile("" : "+s"(dup_same), "+s"(dup_cross));
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
     V5_TICK(t2);
-    const uint32_t commit_slot = sel(ctxm, id, (uint32_t)kNumCtx);  // a lane without a context writes the pad word
-    if (special != 0) {
-      quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
-      rctx[commit_slot] = st_v;
-    } else if (dup_same != 0) {
-      quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
-      rctx[commit_slot] = st_v;
-    } else {
-      // no context twice within a half: the group's bins read the states as they stand, one update per lane afterwards
-      uint32_t kq_v, sx_v;
-      quad_dec_derive(st_v, kq_v, sx_v);
-#define QFAST(I) quad_dec_step_fast<I>(f, kq_v, sx_v, bits, w)
-      QFAST(0); QFAST(1); QFAST(2); QFAST(3); QFAST(4); QFAST(5); QFAST(6); QFAST(7);
-      if (dup_cross != 0) {
-        // a context of the first half comes again in the second: its update goes through the context store in between
-        const uint32_t first_half = neg_mask(j - 8u);  // ~0 in lanes 0..7
-        rctx[sel(first_half, commit_slot, (uint32_t)kNumCtx)] = quad_dec_commit(st_v, r0_v, a_v, (bits >> j) & 1u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the re-read below sees the other lanes' stores
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        st_v = rctx[slot] & ctxm;
-        quad_dec_derive(st_v, kq_v, sx_v);
-        QFAST(8); QFAST(9); QFAST(10); QFAST(11); QFAST(12); QFAST(13); QFAST(14); QFAST(15);
-        rctx[sel(first_half, (uint32_t)kNumCtx, commit_slot)] = quad_dec_commit(st_v, r0_v, a_v, (bits >> j) & 1u);
-      } else {
-        QFAST(8); QFAST(9); QFAST(10); QFAST(11); QFAST(12); QFAST(13); QFAST(14); QFAST(15);
-        rctx[commit_slot] = quad_dec_commit(st_v, r0_v, a_v, (bits >> j) & 1u);
-      }
-#undef QFAST
-    }
+    if (special == 0) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
+    else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
     V5_TICK(t3);
     const uint32_t my_bin = (bits >> j) & 1u;
+    rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
     V5_TICK(t4);
