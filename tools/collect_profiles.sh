@@ -19,7 +19,16 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write
 find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 for k in fetch write; do
   f=$(find "$OUT/pmc_$k" -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|cabac" "$f" | cut -d, -f7,9,16,17 > "$OUT/pmc_$k.csv"
+  [ -n "$f" ] && python3 - "$f" "$OUT/pmc_$k.csv" <<'PY'
+import csv, sys
+with open(sys.argv[1]) as f, open(sys.argv[2], "w", newline="") as g:
+    r = csv.DictReader(f)
+    w = csv.writer(g)
+    w.writerow(["Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value"])
+    for row in r:
+        if "cabac" in row["Kernel_Name"]:
+            w.writerow([row["Grid_Size"], row["Kernel_Name"], row["Counter_Name"], row["Counter_Value"]])
+PY
 done
 rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write"
 ls -la "$OUT"
