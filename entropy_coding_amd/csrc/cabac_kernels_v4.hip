@@ -860,29 +860,41 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   const uint32_t last_rec = n != 0 ? n - 1u : 0u;
   uint32_t next_rec = rec_safe[min(j, last_rec)];
   uint32_t prev_bin = 0, prev_idx = ~0u;  // the bins of the previous step, not yet stored
+  // The record ids of a step and the states of their contexts are fetched at the END of the step before (the records
+  // were requested a whole step earlier; the context store has just been written back): the LDS round trip and the
+  // dependent id / slot arithmetic are off the top of the step.
+  uint32_t cur_id, cur_stored, cur_rates;
+  auto fetch_contexts = [&](uint32_t base) {
+    uint32_t r = next_rec;            // loaded one step ago
+    asm volatile("" : "+v"(r));       // the wait for that load goes HERE
+    const uint32_t actm = neg_mask(base + j - n);                  // ~0: a record of this substream
+    cur_id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);             // past the end: an id that is nothing
+    const uint32_t slot = min(cur_id, (uint32_t)kNumCtx);          // slot kNumCtx is the row's pad word
+    cur_stored = rctx[slot];
+    cur_rates = rrate[slot];
+    next_rec = rec_safe[min(base + 16u + j, last_rec)];            // the records of the step after
+  };
+  fetch_contexts(0);
   for (uint32_t base = 0; base < max_n; base += 16) {
     // The fields of this step's record, as 0 / ~0 masks from arithmetic: a boolean expression would become a lane
     // mask in SGPRs, and every scalar instruction combining such masks waits ~55 cycles for the vector compare.
     V5_TICK(t0);
-    uint32_t r = next_rec;  // loaded one step ago
-    asm volatile("" : "+v"(r));  // the wait for that load goes HERE ...
     V5_TICK(t1);
-    // ... and the bins of the previous step are stored only now: loads and stores share one in-order counter, so a
-    // store issued at the end of a step would still be in flight at this wait and add its whole latency to every step
-    // (the same wait covers the input block requested a step ago: into the ring with it before anything new is issued)
+    // The bins of the previous step are stored only now, after the wait at the end of that step: loads and stores share
+    // one in-order counter, so a store issued before a wait would add its whole latency to it (the same goes for the
+    // input block requested a step ago: into the ring with it before anything new is issued)
     if ((base & 48u) == 16u) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
     if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
     if ((base & 48u) == 0u) quad_dec_stage_load(w, j);    // steps 0, 4, 8, ...: request a block of input
-    const uint32_t actm = neg_mask(base + j - n);                        // ~0: a record of this substream
-    const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);        // past the end: an id that is nothing
+    const uint32_t actm = neg_mask(base + j - n);
+    const uint32_t id = cur_id;
     const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
     // asked first, needed last (the choice of the step variant): the branch finds the answer waiting
     uint64_t special = __ballot((trm_m | aln_m) != 0);
     asm volatile("" : "+s"(special));
     const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);              // id < 379
     bad |= actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
-    const uint32_t slot = min(id, (uint32_t)kNumCtx);  // slot kNumCtx is the row's pad word
-    const uint32_t stored = rctx[slot], rates = rrate[slot];
+    const uint32_t stored = cur_stored, rates = cur_rates;
     uint32_t st_v = stored & ctxm;
     const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
@@ -895,7 +907,6 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     f.ntrm = ~trm_m;
     f.alm = aln_m;
     f.key = sel(ctxm, id, 0x200u + j);
-    next_rec = rec_safe[min(base + 16u + j, last_rec)];  // prefetch the next step's records
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
     V5_TICK(t2);
     if (special == 0) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
@@ -905,6 +916,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
+    fetch_contexts(base + 16u);                     // the next step's ids and context states
     V5_TICK(t4);
     if (wave == 0) {
       V5_ADD(8, t0, t1);   // waiting for the record
