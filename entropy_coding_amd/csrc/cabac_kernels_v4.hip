@@ -612,6 +612,268 @@ __global__ __launch_bounds__(192 * U) void encode_kernel_v5(uint32_t n_sub, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// v6: the three-wave encoder with `low` taken out of the chain wave.
+//
+// In v5 the chain wave — the wave that sets the pace — spends 9 of its 23 instructions per bin on the code value: the
+// addend, the 64-bit shift-and-add, the count of pending bits.  None of that feeds back into the range recurrence.  Here
+// the chain wave only runs the range recurrence (14 instructions per bin) and leaves, per bin, the twelve bits the code
+// value needs — rm (the MPS sub-range, nine bits) and the renormalisation shift (three) — in eight row-uniform registers
+// it posts once per 16-bin step.  The output wave rebuilds the code value from them, exactly, with the lanes:
+//   low' = (low << sh) + term per bin  (arith_codec.cpp:389-399, :553-582)   =>   over a step
+//   new  = (acc << S) + sum_I term_I << (sh_{I+1} + .. + sh_15),   S = sh_0 + .. + sh_15,
+// a sum of sixteen shifted 16-bit terms into a number of up to 138 bits: lane I forms (term_I, sh_I) of its bin, and a
+// four-level tree over the row (row_shr 1, 2, 4, 8) combines neighbouring segments — (left << S_right) + right — in 64,
+// 64, 96 and 160 bits; the remainder carried from the step before (9 bits, the bits of the unfinished 16-bit unit and a
+// carry) enters as part of lane 0's term.  All carries inside `new` are resolved by the exact additions; the one carry
+// that can leave its top lands on the buffered unit, as in writeOut (arith_codec.cpp:524-546).  The whole 16-bit units
+// are then cut off the top by the lanes (lane k takes unit k) and go through v5's emission (quad_emit_units).
+struct QuadRngCap {
+  uint32_t w[8];  // bins 2k (low half) and 2k + 1 (high half): rm | shift << 9
+};
+
+template <int I, bool kAlign>
+__device__ __forceinline__ void quad_rng_step(const QuadEncInfo &f, uint32_t &range, QuadRngCap &cap) {
+  const uint32_t k = row_bcast<I>(f.k), c2 = row_bcast<I>(f.c2), lpsm = row_bcast<I>(f.lpsm);
+  const uint32_t t = (__umul24((range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+  const uint32_t rm = range - t;
+  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23);  // getRenormBitsLPS; masked out when t == 0
+  const uint32_t nm = (rm >> 8) ^ 1u;                     // rm < 512: 1 iff rm < 256
+  const uint32_t nb = sel(lpsm, nl, nm);
+  range = sel(lpsm, t, rm) << nb;
+  if (kAlign) range = sel(row_bcast<I>(f.alm), 256u, range);
+  const uint32_t w = rm | (nb << 9);
+  if (I & 1) cap.w[I >> 1] |= w << 16;
+  else cap.w[I >> 1] = w;
+}
+
+template <bool kAlign>
+__device__ __forceinline__ void quad_rng_steps(const QuadEncInfo &f, uint32_t &range, QuadRngCap &cap) {
+#define QSTEP(I) quad_rng_step<I, kAlign>(f, range, cap)
+  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
+  QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+#undef QSTEP
+}
+
+__device__ __forceinline__ uint64_t shl64(uint32_t lo, uint32_t hi, uint32_t n) { return (((uint64_t)hi << 32) | lo) << n; }
+
+// The code value of one step for the four rows (see above).  In: this lane's bin (w12 = rm | shift << 9, its flags in
+// `info` as quad_phase_a packs them), the row's remainder `acc` (9 + rem bits and a possible carry above).  Out, in lane 15
+// of the row (the tree's root): the five words of `new`; in every lane: S.
+__device__ __forceinline__ uint32_t quad_low_tree(uint32_t w12, uint32_t info, uint32_t acc, uint32_t j, uint32_t (&out)[5]) {
+  const uint32_t rm = w12 & 0x1ffu, nb = (w12 >> 9) & 7u;
+  const uint32_t lpsm = bit_mask<9>(info), pem = bit_mask<11>(info), ep = (info >> 10) & 1u;
+  const uint32_t term = ((rm & lpsm) << nb) | (rm & pem);  // what the bin adds to low after its shift
+  uint32_t s = nb + ep;                                    // ... and the shift itself
+  // level 0: the remainder of the step before rides on bin 0
+  const uint32_t acc0 = acc & neg_mask(j - 1u);  // lane 0 only
+  uint64_t v = shl64(acc0, 0u, s) + term;                  // < 2^33
+  uint32_t v0 = (uint32_t)v, v1 = (uint32_t)(v >> 32);
+  // level 1: bins (2m, 2m + 1) in lane 2m + 1
+  {
+    const uint32_t p0 = row_shr<1>(v0), p1 = row_shr<1>(v1), ps = row_shr<1>(s);
+    v = shl64(p0, p1, s) + v;                              // < 2^41
+    s += ps;
+    v0 = (uint32_t)v;
+    v1 = (uint32_t)(v >> 32);
+  }
+  // level 2: four bins in lane 4m + 3
+  {
+    const uint32_t p0 = row_shr<2>(v0), p1 = row_shr<2>(v1), ps = row_shr<2>(s);
+    v = shl64(p0, p1, s) + v;                              // < 2^56
+    s += ps;
+    v0 = (uint32_t)v;
+    v1 = (uint32_t)(v >> 32);
+  }
+  // level 3: eight bins in lane 8m + 7, three words
+  uint32_t v2;
+  {
+    const uint32_t p0 = row_shr<4>(v0), p1 = row_shr<4>(v1), ps = row_shr<4>(s);  // s <= 28 here
+    const uint64_t lo = shl64(p0, p1, s), hi = shl64(p1, 0u, s);                  // bits 0..63 and 32..95 of p << s
+    const uint64_t a = (lo & 0xffffffffull) + v0;
+    const uint64_t b = (lo >> 32) + v1 + (a >> 32);
+    v0 = (uint32_t)a;
+    v1 = (uint32_t)b;
+    v2 = (uint32_t)(hi >> 32) + (uint32_t)(b >> 32);
+    s += ps;
+  }
+  // level 4: the sixteen bins in lane 15, five words
+  {
+    const uint32_t p0 = row_shr<8>(v0), p1 = row_shr<8>(v1), p2 = row_shr<8>(v2), ps = row_shr<8>(s);  // s <= 56 here
+    const uint32_t wide = neg_mask(31u - s);  // ~0: shift by 32 or more
+    const uint32_t y0 = p0 & ~wide, y1 = sel(wide, p0, p1), y2 = sel(wide, p1, p2), y3 = p2 & wide, b = s & 31u;
+    const uint64_t f01 = shl64(y0, y1, b), f12 = shl64(y1, y2, b), f23 = shl64(y2, y3, b), f34 = shl64(y3, 0u, b);
+    const uint64_t a0 = (f01 & 0xffffffffull) + v0;
+    const uint64_t a1 = (f01 >> 32) + v1 + (a0 >> 32);
+    const uint64_t a2 = (f12 >> 32) + v2 + (a1 >> 32);
+    const uint64_t a3 = (f23 >> 32) + (a2 >> 32);
+    out[0] = (uint32_t)a0;
+    out[1] = (uint32_t)a1;
+    out[2] = (uint32_t)a2;
+    out[3] = (uint32_t)a3;
+    out[4] = (uint32_t)(f34 >> 32) + (uint32_t)(a3 >> 32);
+    s += ps;
+  }
+  return row_bcast<15>(s);
+}
+
+template <int U>
+__global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                            const uint16_t *__restrict__ records,
+                                                            uint8_t *__restrict__ bytes,
+                                                            cabac_substream_result *__restrict__ results) {
+  __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
+  __shared__ uint32_t mail_all[U][2][64];
+  __shared__ __attribute__((aligned(16))) uint32_t cap_post[U][2][kQuadSubs][8];   // chain -> output: 16 x (rm | shift << 9) per row and step
+  __shared__ uint32_t flag_post[U][2][64];            // ... and the bins' flag words
+  __shared__ uint32_t new_words[U][kQuadSubs][8];     // the step's code value, for the lanes that cut the units off it
+  __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
+  __shared__ uint32_t bad_rows[U];
+  __shared__ uint32_t wg_max_n;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: output wave
+  const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
+  const bool live = sub < n_sub;
+  const cabac_substream_desc d = desc[live ? sub : 0];
+  const uint32_t n = live ? d.n_records : 0u;
+  uint32_t (*mail)[64] = mail_all[unit];
+
+  if (threadIdx.x == 0) wg_max_n = 0;
+  __syncthreads();
+  atomicMax(&wg_max_n, n);
+  __syncthreads();
+  const uint32_t max_n = wg_max_n;
+
+  if (role == 0) {
+    // ---- context wave: exactly v5's -----------------------------------------------------------------
+    const uint16_t *rec = records + d.rec_offset;
+    uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
+    quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+    uint32_t bad = 0;
+    const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
+    const uint32_t last_rec = n != 0 ? n - 1u : 0u;
+    const uint32_t cur_rec = rec_safe[min(j, last_rec)];
+    uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
+    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
+    __syncthreads();
+    uint32_t slot = 1;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      const uint32_t r = next_rec;
+      next_rec = rec_safe[min(base + 32u + j, last_rec)];
+      mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
+      slot ^= 1u;
+      __syncthreads();
+    }
+    const uint64_t bad_mask = __ballot(bad != 0);
+    if (lane == 0) {
+      uint32_t rows = 0;
+      for (uint32_t k = 0; k < 4; k++) rows |= ((bad_mask >> (16u * k)) & 0xffffull) ? (1u << k) : 0u;
+      bad_rows[unit] = rows;
+    }
+    __syncthreads();
+  } else if (role == 1) {
+    // ---- chain wave: the range recurrence and nothing else -----------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t range = 510;  // start(), arith_codec.cpp:329-337
+    __syncthreads();
+    uint32_t slot = 0;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      const uint32_t info = mail[slot][lane];
+      const QuadEncInfo f = quad_unpack(info);
+      QuadRngCap cap;
+      if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
+      else quad_rng_steps<true>(f, range, cap);
+      // row-uniform: every lane of the row writes the same words (lanes 0..7 one each would need a register index)
+      uint4 *dst = reinterpret_cast<uint4 *>(cap_post[unit][slot][row]);
+      dst[0] = make_uint4(cap.w[0], cap.w[1], cap.w[2], cap.w[3]);
+      dst[1] = make_uint4(cap.w[4], cap.w[5], cap.w[6], cap.w[7]);
+      flag_post[unit][slot][lane] = info;
+      slot ^= 1u;
+      __syncthreads();
+    }
+    __syncthreads();
+  } else {
+    // ---- output wave: while the chain wave codes step base, rebuild the code value of step base - 16 from its
+    // post, cut the whole units off its top and list them; they are written out one iteration later -------------
+    QuadEnc e;
+    e.low = 0;
+    e.range = 0;
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    uint32_t *list = unit_list[unit][row];
+    uint32_t *nw = new_words[unit][row];
+    uint32_t acc = 0, rem = 0;  // row-uniform: the low 9 + rem bits of the code value (and a carry above), rem < 16
+    auto list_step = [&](uint32_t slot) {
+      const uint32_t pair = cap_post[unit][slot][row][j >> 1];
+      const uint32_t w12 = (j & 1u) ? pair >> 16 : pair & 0xffffu;
+      uint32_t words[5];
+      const uint32_t s_total = quad_low_tree(w12, flag_post[unit][slot][lane], acc, j, words);
+      // lane 15 holds the number: through LDS to the lanes that take the units (the others write a spare slot)
+      const uint32_t at = j == 15u ? 0u : 5u;  // lanes 0..14 dump into words 5..7 (never read)
+      nw[at] = words[0];
+      nw[min(at + 1u, 7u)] = words[1];
+      nw[min(at + 2u, 7u)] = words[2];
+      nw[min(at + 3u, 7u)] = words[3];
+      nw[min(at + 4u, 7u)] = words[4];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 15's words, read by the other lanes below
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t pendn = rem + s_total, m = pendn >> 4;  // whole units in this step: at most 7
+      rem = pendn & 15u;
+      const uint32_t base_off = 9u + rem;
+      // unit k (k = 0 first in the stream) sits at bit base_off + 16 * (m - 1 - k); the first one with the carry above it
+      const uint32_t o = base_off + 16u * ((m - 1u - min(j, m - 1u)) & 7u);
+      const uint32_t wi = min(o >> 5, 3u);
+      const uint64_t two = ((uint64_t)nw[wi + 1u] << 32) | nw[wi];
+      const uint32_t lead = (uint32_t)(two >> (o - 32u * wi)) & (j == 0u ? 0x1ffffu : 0xffffu);
+      const uint32_t low0 = nw[0];
+      acc = m != 0u ? low0 & ((1u << base_off) - 1u) : low0;
+      list[j < m ? j : kUnitDump] = lead;
+      QuadUnits u;
+      u.m = m;
+      const uint32_t room = e.cap - e.pos - 2u * m;  // negative: the buffer would overflow
+      const uint32_t rowodd = neg_mask(0u - m) & (neg_mask(0u - ((uint32_t)e.nbuf ^ 1u)) | neg_mask(room));
+      u.odd_rows = __ballot(rowodd != 0);
+      u.store_lanes = __ballot(live && j < m);
+      return u;
+    };
+    __syncthreads();
+    uint32_t slot = 1;
+    QuadUnits units;
+    units.m = 0;
+    units.odd_rows = 0;
+    units.store_lanes = 0;
+    bool listed = false;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      if (listed) quad_emit_units(e, units, j, list, writer);
+      listed = base != 0;
+      if (listed) units = list_step(slot);
+      slot ^= 1u;
+      __syncthreads();
+    }
+    __syncthreads();  // the chain wave has posted its last step; bad_rows is written
+    if (listed) quad_emit_units(e, units, j, list, writer);
+    if (max_n != 0) {
+      units = list_step(slot);
+      quad_emit_units(e, units, j, list, writer);
+    }
+    e.low = acc;
+    e.pend = (int32_t)rem;
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    if (writer) {
+      cabac_substream_result res;
+      res.n_bits = n_bits;
+      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
+      results[sub] = res;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // decode
 
 struct QuadDec {   // row-uniform values
@@ -1085,6 +1347,15 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
   if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
   else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(384), 0, st, n_sub, desc, records, bytes, results);
   else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
+  const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
+  const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
+  if (units_on_chip >= 1024u) hipLaunchKernelGGL(encode_kernel_v6<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL(encode_kernel_v6<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 
