@@ -716,21 +716,28 @@ __device__ __forceinline__ uint32_t quad_low_tree(uint32_t w12, uint32_t info, u
   return row_bcast<15>(s);
 }
 
+// Four waves per unit of four substreams: context wave (v5's), chain wave (range only), low wave (the code value of a
+// step -> its 16-bit units) and emit wave (v5's emission: delayed carry, 0xFFFF runs, byte stores).  Measured with the
+// code value and the emission in ONE output wave, that wave became the longest (its tree and its LDS round trips in a row:
+// 1.02 ms against v5's 0.98); apart, each fits beside the chain wave.  One workgroup barrier per 16-bin step; step k is
+// coded by the chain wave in iteration k, turned into units in iteration k + 1 and written out in iteration k + 2.
 template <int U>
-__global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+__global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                             const uint16_t *__restrict__ records,
                                                             uint8_t *__restrict__ bytes,
                                                             cabac_substream_result *__restrict__ results) {
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t mail_all[U][2][64];
-  __shared__ __attribute__((aligned(16))) uint32_t cap_post[U][2][kQuadSubs][8];   // chain -> output: 16 x (rm | shift << 9) per row and step
-  __shared__ uint32_t flag_post[U][2][64];            // ... and the bins' flag words
+  __shared__ __attribute__((aligned(16))) uint32_t cap_post[U][2][kQuadSubs][8];  // chain -> low: 16 x (rm | shift << 9) per row and step
+  __shared__ uint32_t flag_post[U][2][64];                                        // ... and the bins' flag words
   __shared__ uint32_t new_words[U][kQuadSubs][8];     // the step's code value, for the lanes that cut the units off it
-  __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
+  __shared__ uint32_t unit_list[U][2][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
+  __shared__ uint32_t unit_count[U][2][kQuadSubs];
+  __shared__ uint32_t fin_acc[U][kQuadSubs], fin_rem[U][kQuadSubs];
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
-  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: output wave
+  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: low wave, 3: emit wave
   const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -742,6 +749,7 @@ __global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, cons
   atomicMax(&wg_max_n, n);
   __syncthreads();
   const uint32_t max_n = wg_max_n;
+  // every role: one barrier before the loop, one per step, two after it
 
   if (role == 0) {
     // ---- context wave: exactly v5's -----------------------------------------------------------------
@@ -770,6 +778,7 @@ __global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, cons
       bad_rows[unit] = rows;
     }
     __syncthreads();
+    __syncthreads();
   } else if (role == 1) {
     // ---- chain wave: the range recurrence and nothing else -----------------------------------------------
     __builtin_amdgcn_s_setprio(3);
@@ -791,20 +800,9 @@ __global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, cons
       __syncthreads();
     }
     __syncthreads();
-  } else {
-    // ---- output wave: while the chain wave codes step base, rebuild the code value of step base - 16 from its
-    // post, cut the whole units off its top and list them; they are written out one iteration later -------------
-    QuadEnc e;
-    e.low = 0;
-    e.range = 0;
-    e.pend = 0;
-    e.buf = 0;
-    e.nbuf = 0;
-    e.pos = 0;
-    e.dst = bytes + d.byte_offset;
-    e.cap = live ? d.byte_capacity : 0u;
-    const bool writer = live && j == 0;
-    uint32_t *list = unit_list[unit][row];
+    __syncthreads();
+  } else if (role == 2) {
+    // ---- low wave: in iteration k the code value of step k - 1 and its whole units -------------------------
     uint32_t *nw = new_words[unit][row];
     uint32_t acc = 0, rem = 0;  // row-uniform: the low 9 + rem bits of the code value (and a carry above), rem < 16
     auto list_step = [&](uint32_t slot) {
@@ -832,37 +830,59 @@ __global__ __launch_bounds__(192 * U) void encode_kernel_v6(uint32_t n_sub, cons
       const uint32_t lead = (uint32_t)(two >> (o - 32u * wi)) & (j == 0u ? 0x1ffffu : 0xffffu);
       const uint32_t low0 = nw[0];
       acc = m != 0u ? low0 & ((1u << base_off) - 1u) : low0;
-      list[j < m ? j : kUnitDump] = lead;
-      QuadUnits u;
-      u.m = m;
-      const uint32_t room = e.cap - e.pos - 2u * m;  // negative: the buffer would overflow
-      const uint32_t rowodd = neg_mask(0u - m) & (neg_mask(0u - ((uint32_t)e.nbuf ^ 1u)) | neg_mask(room));
-      u.odd_rows = __ballot(rowodd != 0);
-      u.store_lanes = __ballot(live && j < m);
-      return u;
+      unit_list[unit][slot][row][j < m ? j : kUnitDump] = lead;
+      if (j == 0u) unit_count[unit][slot][row] = m;
     };
     __syncthreads();
     uint32_t slot = 1;
-    QuadUnits units;
-    units.m = 0;
-    units.odd_rows = 0;
-    units.store_lanes = 0;
-    bool listed = false;
     for (uint32_t base = 0; base < max_n; base += 16) {
-      if (listed) quad_emit_units(e, units, j, list, writer);
-      listed = base != 0;
-      if (listed) units = list_step(slot);
+      if (base != 0) list_step(slot);
       slot ^= 1u;
       __syncthreads();
     }
-    __syncthreads();  // the chain wave has posted its last step; bad_rows is written
-    if (listed) quad_emit_units(e, units, j, list, writer);
-    if (max_n != 0) {
-      units = list_step(slot);
-      quad_emit_units(e, units, j, list, writer);
+    if (max_n != 0) list_step(slot);
+    if (j == 0u) {
+      fin_acc[unit][row] = acc;
+      fin_rem[unit][row] = rem;
     }
-    e.low = acc;
-    e.pend = (int32_t)rem;
+    __syncthreads();
+    __syncthreads();
+  } else {
+    // ---- emit wave: in iteration k the units of step k - 2 -----------------------------------------------
+    QuadEnc e;
+    e.low = 0;
+    e.range = 0;
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    auto emit_step = [&](uint32_t slot) {
+      const uint32_t *list = unit_list[unit][slot][row];
+      QuadUnits u;
+      u.m = unit_count[unit][slot][row];
+      const uint32_t room = e.cap - e.pos - 2u * u.m;  // negative: the buffer would overflow
+      const uint32_t rowodd = neg_mask(0u - u.m) & (neg_mask(0u - ((uint32_t)e.nbuf ^ 1u)) | neg_mask(room));
+      u.odd_rows = __ballot(rowodd != 0);
+      u.store_lanes = __ballot(live && j < u.m);
+      quad_emit_units(e, u, j, list, writer);
+    };
+    __syncthreads();
+    uint32_t slot = 0;
+    for (uint32_t base = 0; base < max_n; base += 16) {
+      if (base >= 32u) emit_step(slot);
+      slot ^= 1u;
+      __syncthreads();
+    }
+    if (max_n > 16u) emit_step(slot);  // the step before the last
+    slot ^= 1u;
+    __syncthreads();
+    if (max_n != 0) emit_step(slot);   // the last step
+    __syncthreads();
+    e.low = fin_acc[unit][row];
+    e.pend = (int32_t)fin_rem[unit][row];
     const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
     if (writer) {
       cabac_substream_result res;
@@ -1354,8 +1374,8 @@ hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substrea
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
   const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
-  if (units_on_chip >= 1024u) hipLaunchKernelGGL(encode_kernel_v6<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
-  else hipLaunchKernelGGL(encode_kernel_v6<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
+  if (units_on_chip >= 1024u) hipLaunchKernelGGL(encode_kernel_v6<4>, dim3((units + 3) / 4), dim3(1024), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL(encode_kernel_v6<1>, dim3(units), dim3(256), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 
