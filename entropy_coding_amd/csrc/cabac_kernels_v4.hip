@@ -656,35 +656,47 @@ __device__ __forceinline__ void quad_rng_steps(const QuadEncInfo &f, uint32_t &r
 
 __device__ __forceinline__ uint64_t shl64(uint32_t lo, uint32_t hi, uint32_t n) { return (((uint64_t)hi << 32) | lo) << n; }
 
-// The code value of one step for the four rows (see above).  In: this lane's bin (w12 = rm | shift << 9, its flags in
-// `info` as quad_phase_a packs them), the row's remainder `acc` (9 + rem bits and a possible carry above).  Out, in lane 15
-// of the row (the tree's root): the five words of `new`; in every lane: S.
-__device__ __forceinline__ uint32_t quad_low_tree(uint32_t w12, uint32_t info, uint32_t acc, uint32_t j, uint32_t (&out)[5]) {
+// The code value of one step for the four rows (see above), in two parts.  Part 1 (chain wave, which has the time):
+// lane I picks the twelve bits of its bin out of the row-uniform capture registers, forms (term, shift) and combines four
+// bins at a time: lanes 4m + 3 end up with (value < 2^56, shift) of bins 4m .. 4m + 3.
+__device__ __forceinline__ void quad_low_quads(const QuadRngCap &cap, uint32_t info, uint32_t j, uint32_t &v0, uint32_t &v1,
+                                               uint32_t &s) {
+  const uint32_t h = j >> 1;
+  const uint32_t a0 = (h & 1u) ? cap.w[1] : cap.w[0], a1 = (h & 1u) ? cap.w[3] : cap.w[2], a2 = (h & 1u) ? cap.w[5] : cap.w[4],
+                 a3 = (h & 1u) ? cap.w[7] : cap.w[6];
+  const uint32_t b0 = (h & 2u) ? a1 : a0, b1 = (h & 2u) ? a3 : a2;
+  const uint32_t pair = (h & 4u) ? b1 : b0;
+  const uint32_t w12 = (j & 1u) ? pair >> 16 : pair;
   const uint32_t rm = w12 & 0x1ffu, nb = (w12 >> 9) & 7u;
   const uint32_t lpsm = bit_mask<9>(info), pem = bit_mask<11>(info), ep = (info >> 10) & 1u;
   const uint32_t term = ((rm & lpsm) << nb) | (rm & pem);  // what the bin adds to low after its shift
-  uint32_t s = nb + ep;                                    // ... and the shift itself
-  // level 0: the remainder of the step before rides on bin 0
-  const uint32_t acc0 = acc & neg_mask(j - 1u);  // lane 0 only
-  uint64_t v = shl64(acc0, 0u, s) + term;                  // < 2^33
-  uint32_t v0 = (uint32_t)v, v1 = (uint32_t)(v >> 32);
-  // level 1: bins (2m, 2m + 1) in lane 2m + 1
-  {
-    const uint32_t p0 = row_shr<1>(v0), p1 = row_shr<1>(v1), ps = row_shr<1>(s);
-    v = shl64(p0, p1, s) + v;                              // < 2^41
+  s = nb + ep;                                             // ... and the shift itself
+  uint64_t v = term;
+  {  // bins (2m, 2m + 1) in lane 2m + 1
+    const uint32_t p0 = row_shr<1>(term), ps = row_shr<1>(s);
+    v = shl64(p0, 0u, s) + v;                              // < 2^24
     s += ps;
-    v0 = (uint32_t)v;
-    v1 = (uint32_t)(v >> 32);
   }
-  // level 2: four bins in lane 4m + 3
-  {
-    const uint32_t p0 = row_shr<2>(v0), p1 = row_shr<2>(v1), ps = row_shr<2>(s);
-    v = shl64(p0, p1, s) + v;                              // < 2^56
+  v0 = (uint32_t)v;
+  {  // four bins in lane 4m + 3
+    const uint32_t p0 = row_shr<2>(v0), ps = row_shr<2>(s);
+    v = shl64(p0, 0u, s) + v;                              // < 2^39
     s += ps;
-    v0 = (uint32_t)v;
-    v1 = (uint32_t)(v >> 32);
   }
-  // level 3: eight bins in lane 8m + 7, three words
+  v0 = (uint32_t)v;
+  v1 = (uint32_t)(v >> 32);
+}
+
+// Part 2 (low wave): the four quads and the row's remainder `acc` (9 + rem bits and a possible carry above) -> the five
+// words of `new`, in every lane of the row, and S.
+__device__ __forceinline__ uint32_t quad_low_join(uint32_t v0, uint32_t v1, uint32_t s, uint32_t acc, uint32_t j, uint32_t (&out)[5]) {
+  // the remainder rides on the first quad: (acc << S_quad0) + V_quad0, acc < 2^25, S_quad0 <= 28
+  {
+    const uint64_t a = shl64(acc & neg_mask(j - 4u), 0u, s) + ((((uint64_t)v1) << 32) | v0);  // lanes 0..3; < 2^54
+    v0 = (uint32_t)a;
+    v1 = (uint32_t)(a >> 32);
+  }
+  // eight bins in lane 8m + 7, three words
   uint32_t v2;
   {
     const uint32_t p0 = row_shr<4>(v0), p1 = row_shr<4>(v1), ps = row_shr<4>(s);  // s <= 28 here
@@ -696,7 +708,8 @@ __device__ __forceinline__ uint32_t quad_low_tree(uint32_t w12, uint32_t info, u
     v2 = (uint32_t)(hi >> 32) + (uint32_t)(b >> 32);
     s += ps;
   }
-  // level 4: the sixteen bins in lane 15, five words
+  // the sixteen bins in lane 15, five words
+  uint32_t w0, w1, w2, w3, w4;
   {
     const uint32_t p0 = row_shr<8>(v0), p1 = row_shr<8>(v1), p2 = row_shr<8>(v2), ps = row_shr<8>(s);  // s <= 56 here
     const uint32_t wide = neg_mask(31u - s);  // ~0: shift by 32 or more
@@ -706,13 +719,18 @@ __device__ __forceinline__ uint32_t quad_low_tree(uint32_t w12, uint32_t info, u
     const uint64_t a1 = (f01 >> 32) + v1 + (a0 >> 32);
     const uint64_t a2 = (f12 >> 32) + v2 + (a1 >> 32);
     const uint64_t a3 = (f23 >> 32) + (a2 >> 32);
-    out[0] = (uint32_t)a0;
-    out[1] = (uint32_t)a1;
-    out[2] = (uint32_t)a2;
-    out[3] = (uint32_t)a3;
-    out[4] = (uint32_t)(f34 >> 32) + (uint32_t)(a3 >> 32);
+    w0 = (uint32_t)a0;
+    w1 = (uint32_t)a1;
+    w2 = (uint32_t)a2;
+    w3 = (uint32_t)a3;
+    w4 = (uint32_t)(f34 >> 32) + (uint32_t)(a3 >> 32);
     s += ps;
   }
+  out[0] = row_bcast<15>(w0);
+  out[1] = row_bcast<15>(w1);
+  out[2] = row_bcast<15>(w2);
+  out[3] = row_bcast<15>(w3);
+  out[4] = row_bcast<15>(w4);
   return row_bcast<15>(s);
 }
 
@@ -728,9 +746,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
                                                             cabac_substream_result *__restrict__ results) {
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t mail_all[U][2][64];
-  __shared__ __attribute__((aligned(16))) uint32_t cap_post[U][2][kQuadSubs][8];  // chain -> low: 16 x (rm | shift << 9) per row and step
-  __shared__ uint32_t flag_post[U][2][64];                                        // ... and the bins' flag words
-  __shared__ uint32_t new_words[U][kQuadSubs][8];     // the step's code value, for the lanes that cut the units off it
+  __shared__ uint32_t quad_post[U][2][3][64];  // chain -> low: per lane (value low, value high, shift) of its four-bin segment
   __shared__ uint32_t unit_list[U][2][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
   __shared__ uint32_t unit_count[U][2][kQuadSubs];
   __shared__ uint32_t fin_acc[U][kQuadSubs], fin_rem[U][kQuadSubs];
@@ -767,9 +783,14 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     for (uint32_t base = 0; base < max_n; base += 16) {
       const uint32_t r = next_rec;
       next_rec = rec_safe[min(base + 32u + j, last_rec)];
+      V5_TICK(t2);
       mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
       slot ^= 1u;
+      V5_TICK(t3);
       __syncthreads();
+      V5_TICK(t4);
+      V5_ADD(2, t2, t3);  // phase (a)
+      V5_ADD(3, t3, t4);  // waiting at the barrier
     }
     const uint64_t bad_mask = __ballot(bad != 0);
     if (lane == 0) {
@@ -789,56 +810,56 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       const uint32_t info = mail[slot][lane];
       const QuadEncInfo f = quad_unpack(info);
       QuadRngCap cap;
+      V5_TICK(t0);
       if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
       else quad_rng_steps<true>(f, range, cap);
-      // row-uniform: every lane of the row writes the same words (lanes 0..7 one each would need a register index)
-      uint4 *dst = reinterpret_cast<uint4 *>(cap_post[unit][slot][row]);
-      dst[0] = make_uint4(cap.w[0], cap.w[1], cap.w[2], cap.w[3]);
-      dst[1] = make_uint4(cap.w[4], cap.w[5], cap.w[6], cap.w[7]);
-      flag_post[unit][slot][lane] = info;
+      V5_TICK(t1);
+      uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
+      quad_low_quads(cap, info, j, q0, q1, qs);
+      quad_post[unit][slot][0][lane] = q0;
+      quad_post[unit][slot][1][lane] = q1;
+      quad_post[unit][slot][2][lane] = qs;
       slot ^= 1u;
+      V5_TICK(t1b);
       __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(4, t0, t1);   // chain
+      V5_ADD(5, t1b, t2);  // waiting at the barrier
+      V5_ADD(6, t1, t1b);  // posting
     }
     __syncthreads();
     __syncthreads();
   } else if (role == 2) {
     // ---- low wave: in iteration k the code value of step k - 1 and its whole units -------------------------
-    uint32_t *nw = new_words[unit][row];
     uint32_t acc = 0, rem = 0;  // row-uniform: the low 9 + rem bits of the code value (and a carry above), rem < 16
     auto list_step = [&](uint32_t slot) {
-      const uint32_t pair = cap_post[unit][slot][row][j >> 1];
-      const uint32_t w12 = (j & 1u) ? pair >> 16 : pair & 0xffffu;
-      uint32_t words[5];
-      const uint32_t s_total = quad_low_tree(w12, flag_post[unit][slot][lane], acc, j, words);
-      // lane 15 holds the number: through LDS to the lanes that take the units (the others write a spare slot)
-      const uint32_t at = j == 15u ? 0u : 5u;  // lanes 0..14 dump into words 5..7 (never read)
-      nw[at] = words[0];
-      nw[min(at + 1u, 7u)] = words[1];
-      nw[min(at + 2u, 7u)] = words[2];
-      nw[min(at + 3u, 7u)] = words[3];
-      nw[min(at + 4u, 7u)] = words[4];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 15's words, read by the other lanes below
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t w[5];
+      const uint32_t s_total = quad_low_join(quad_post[unit][slot][0][lane], quad_post[unit][slot][1][lane],
+                                             quad_post[unit][slot][2][lane], acc, j, w);
       const uint32_t pendn = rem + s_total, m = pendn >> 4;  // whole units in this step: at most 7
       rem = pendn & 15u;
       const uint32_t base_off = 9u + rem;
       // unit k (k = 0 first in the stream) sits at bit base_off + 16 * (m - 1 - k); the first one with the carry above it
       const uint32_t o = base_off + 16u * ((m - 1u - min(j, m - 1u)) & 7u);
-      const uint32_t wi = min(o >> 5, 3u);
-      const uint64_t two = ((uint64_t)nw[wi + 1u] << 32) | nw[wi];
-      const uint32_t lead = (uint32_t)(two >> (o - 32u * wi)) & (j == 0u ? 0x1ffffu : 0xffffu);
-      const uint32_t low0 = nw[0];
-      acc = m != 0u ? low0 & ((1u << base_off) - 1u) : low0;
+      const uint32_t wi = o >> 5;  // 0..3
+      const uint32_t lo = wi >= 2u ? (wi == 3u ? w[3] : w[2]) : (wi == 1u ? w[1] : w[0]);
+      const uint32_t hi = wi >= 2u ? (wi == 3u ? w[4] : w[3]) : (wi == 1u ? w[2] : w[1]);
+      const uint32_t lead = (uint32_t)((((uint64_t)hi << 32) | lo) >> (o & 31u)) & (j == 0u ? 0x1ffffu : 0xffffu);
+      acc = m != 0u ? w[0] & ((1u << base_off) - 1u) : w[0];
       unit_list[unit][slot][row][j < m ? j : kUnitDump] = lead;
       if (j == 0u) unit_count[unit][slot][row] = m;
     };
     __syncthreads();
     uint32_t slot = 1;
     for (uint32_t base = 0; base < max_n; base += 16) {
+      V5_TICK(t0);
       if (base != 0) list_step(slot);
       slot ^= 1u;
+      V5_TICK(t1);
       __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(1, t0, t1);   // low wave: code value + units
+      V5_ADD(7, t1, t2);   // its barrier wait
     }
     if (max_n != 0) list_step(slot);
     if (j == 0u) {
@@ -872,9 +893,14 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
     uint32_t slot = 0;
     for (uint32_t base = 0; base < max_n; base += 16) {
+      V5_TICK(t0);
       if (base >= 32u) emit_step(slot);
       slot ^= 1u;
+      V5_TICK(t1);
       __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(0, t0, t1);   // emit wave
+      V5_ADD(12, t1, t2);  // its barrier wait
     }
     if (max_n > 16u) emit_step(slot);  // the step before the last
     slot ^= 1u;

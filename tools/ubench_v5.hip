@@ -54,6 +54,19 @@ int main() {
     }
     printf("kernel %.3f ms; cycles per 16-bin step, workgroup 0: context wave phase(a) %.0f barrier %.0f | chain wave chain %.0f barrier %.0f | output wave emit %.0f list %.0f\n",
            ms, p[2] / g, p[3] / g, p[4] / g, p[5] / g, p[0] / g, p[1] / g);
+    {  // the four-wave encoder (v6), same probes
+      unsigned long long z[16] = {};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), z, sizeof(z));
+      hipEvent_t c, d; (void)hipEventCreate(&c); (void)hipEventCreate(&d);
+      (void)hipEventRecord(c);
+      hipLaunchKernelGGL(encode_kernel_v6<4>, dim3(n_sub / 16), dim3(1024), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+      (void)hipEventRecord(d); (void)hipDeviceSynchronize();
+      float vms; (void)hipEventElapsedTime(&vms, c, d);
+      unsigned long long q[16];
+      (void)hipMemcpyFromSymbol(q, HIP_SYMBOL(g_v5_prof), sizeof(q));
+      printf("v6 kernel %.3f ms; cycles per step, workgroup 0 (sum over its 4 units): context phase(a) %.0f barrier %.0f | chain %.0f post %.0f barrier %.0f | low %.0f barrier %.0f | emit %.0f barrier %.0f\n",
+             vms, q[2] / g, q[3] / g, q[4] / g, q[6] / g, q[5] / g, q[1] / g, q[7] / g, q[0] / g, q[12] / g);
+    }
   }
   return 0;
 }
