@@ -1156,10 +1156,10 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  // auto (measured): the two-wave quad encoder (v5) has the shortest per-substream chain at
-  // every batch size tried (C2: 10, C3: 256, C4: 4 096, C5: 8 192 substreams)
-  if (kind == 6) return launch_encode_v6(st, n_sub, desc, records, bytes, results, in_flight);
-  if (kind == 5 || kind == 0) return launch_encode_v5(st, n_sub, desc, records, bytes, results, in_flight);
+  // auto (measured): the four-wave quad encoder (v6) has the shortest per-substream chain at every batch
+  // size tried (C2: 10, C3: 256, C4: 4 096, C5: 8 192 substreams)
+  if (kind == 6 || kind == 0) return launch_encode_v6(st, n_sub, desc, records, bytes, results, in_flight);
+  if (kind == 5) return launch_encode_v5(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 4) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
   if (kind == 1) {
     hipLaunchKernelGGL(encode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, results);
