@@ -734,6 +734,12 @@ __device__ __forceinline__ uint32_t quad_low_join(uint32_t v0, uint32_t v1, uint
   return row_bcast<15>(s);
 }
 
+#ifndef CABAC_V6_PRIO_CTX
+#define CABAC_V6_PRIO_CTX 0
+#define CABAC_V6_PRIO_CHAIN 3
+#define CABAC_V6_PRIO_LOW 0
+#define CABAC_V6_PRIO_EMIT 0
+#endif
 // Four waves per unit of four substreams: context wave (v5's), chain wave (range only), low wave (the code value of a
 // step -> its 16-bit units) and emit wave (v5's emission: delayed carry, 0xFFFF runs, byte stores).  Measured with the
 // code value and the emission in ONE output wave, that wave became the longest (its tree and its LDS round trips in a row:
@@ -769,6 +775,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
 
   if (role == 0) {
     // ---- context wave: exactly v5's -----------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_CTX);
     const uint16_t *rec = records + d.rec_offset;
     uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
     quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
@@ -789,8 +796,8 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       V5_TICK(t3);
       __syncthreads();
       V5_TICK(t4);
-      V5_ADD(2, t2, t3);  // phase (a)
-      V5_ADD(3, t3, t4);  // waiting at the barrier
+      if (unit == 0) V5_ADD(2, t2, t3);  // phase (a)
+      if (unit == 0) V5_ADD(3, t3, t4);  // waiting at the barrier
     }
     const uint64_t bad_mask = __ballot(bad != 0);
     if (lane == 0) {
@@ -802,7 +809,9 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
   } else if (role == 1) {
     // ---- chain wave: the range recurrence and nothing else -----------------------------------------------
-    __builtin_amdgcn_s_setprio(3);
+    // (v5's chain wave was the longest and got the issue priority; here the low and the emit wave are — few instructions,
+    // but chains of LDS round trips — so they go first whenever they are ready)
+    __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_CHAIN);
     uint32_t range = 510;  // start(), arith_codec.cpp:329-337
     __syncthreads();
     uint32_t slot = 0;
@@ -823,14 +832,15 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       V5_TICK(t1b);
       __syncthreads();
       V5_TICK(t2);
-      V5_ADD(4, t0, t1);   // chain
-      V5_ADD(5, t1b, t2);  // waiting at the barrier
-      V5_ADD(6, t1, t1b);  // posting
+      if (unit == 0) V5_ADD(4, t0, t1);   // chain
+      if (unit == 0) V5_ADD(5, t1b, t2);  // waiting at the barrier
+      if (unit == 0) V5_ADD(6, t1, t1b);  // posting
     }
     __syncthreads();
     __syncthreads();
   } else if (role == 2) {
     // ---- low wave: in iteration k the code value of step k - 1 and its whole units -------------------------
+    __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_LOW);
     uint32_t acc = 0, rem = 0;  // row-uniform: the low 9 + rem bits of the code value (and a carry above), rem < 16
     auto list_step = [&](uint32_t slot) {
       uint32_t w[5];
@@ -858,8 +868,8 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
-      V5_ADD(1, t0, t1);   // low wave: code value + units
-      V5_ADD(7, t1, t2);   // its barrier wait
+      if (unit == 0) V5_ADD(1, t0, t1);   // low wave: code value + units
+      if (unit == 0) V5_ADD(7, t1, t2);   // its barrier wait
     }
     if (max_n != 0) list_step(slot);
     if (j == 0u) {
@@ -870,6 +880,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
   } else {
     // ---- emit wave: in iteration k the units of step k - 2 -----------------------------------------------
+    __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_EMIT);
     QuadEnc e;
     e.low = 0;
     e.range = 0;
@@ -899,8 +910,8 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
-      V5_ADD(0, t0, t1);   // emit wave
-      V5_ADD(12, t1, t2);  // its barrier wait
+      if (unit == 0) V5_ADD(0, t0, t1);   // emit wave
+      if (unit == 0) V5_ADD(12, t1, t2);  // its barrier wait
     }
     if (max_n > 16u) emit_step(slot);  // the step before the last
     slot ^= 1u;
