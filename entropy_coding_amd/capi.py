@@ -34,7 +34,7 @@ EXPORTS = [
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
-    "cabac_hip_host_is_pinned",
+    "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load_library():
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_encode_batch_payload.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
     L.cabac_hip_last_kernel_ms.argtypes = [vp]
     L.cabac_hip_assemble_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint64, vp]
@@ -214,6 +215,18 @@ class CabacHip:
                                            out.ctypes.data, int(bytes_total), res.ctypes.data)
         self._check(rc, allow_substream=not check)
         return out, res
+
+    def encode_batch_payload(self, desc, records, payload, check=True):
+        """cabac_hip_encode_batch_payload: the coded substreams back to back in `payload` (uint8 array, e.g. pinned);
+        returns (offsets uint64[n + 1], results)."""
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        records = np.ascontiguousarray(records, np.uint16)
+        offsets = np.zeros(len(desc) + 1, np.uint64)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        rc = self.L.cabac_hip_encode_batch_payload(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
+                                                   payload.ctypes.data, payload.nbytes, offsets.ctypes.data, res.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return offsets, res
 
     def decode_batch(self, desc, records, data, check=True, bins=None):
         desc = np.ascontiguousarray(desc, DESC_DTYPE)

@@ -307,9 +307,12 @@ std::vector<Chunk> plan_chunks(const cabac_hip_ctx *c, uint32_t n_sub, const cab
     byte_end = std::max<uint64_t>(byte_end, desc[s].byte_offset + desc[s].byte_capacity);
     total += desc[s].n_records;
   }
-  // A chunk must still fill a fair part of the chip on its own (the kernels' time does not shrink below ~1 024
-  // substreams) and be worth its launches: by default one chunk per 1 024 substreams and per 8 M records, at most 4.
-  int want = c->chunks_override > 0 ? c->chunks_override : (int)std::min<uint64_t>(std::min<uint64_t>(n_sub / 1024u, total >> 23), 4u);
+  // The kernels' time does not shrink below ~1 024 substreams (it is the length of the serial chains), and kernels of
+  // different chunks were measured to run one after the other even on separate streams, so a batch of c chunks costs about
+  // copy / c + c x kernel + tail: with the C4 batch (2.35 ms of H2D at 57 GB/s, 0.9 ms of kernel) two chunks are the
+  // minimum (measured: 1 chunk 4.26 ms, 2 chunks 4.08, 4 chunks 4.86, 8 chunks 6.4).  Default: two chunks from 2 048
+  // substreams and 16 M records up, else one; CABAC_HIP_CHUNKS overrides.
+  int want = c->chunks_override > 0 ? c->chunks_override : (n_sub >= 2048u && (total >> 24) != 0u ? 2 : 1);
   want = std::max(1, std::min(want, (int)cabac_hip_ctx::kMaxChunks));
   if (!ordered || (uint32_t)want > n_sub) want = 1;
   std::vector<Chunk> out;
@@ -566,10 +569,14 @@ float cabac_hip_last_kernel_ms(cabac_hip_ctx *c) {
   return ms;
 }
 
-int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                           uint64_t n_records_total, uint8_t *bytes, uint64_t bytes_total,
-                           cabac_substream_result *results) {
+// bytes != NULL: every substream's bytes at its byte_offset (the reference's FIFOs); payload != NULL: the substreams back to
+// back in descriptor order with payload_offsets[0..n_sub] (what OutputBitstream::addSubstream makes of byte-aligned
+// substreams, bit_stream.cpp:139-150)
+static int encode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                             uint64_t n_records_total, uint8_t *bytes, uint64_t bytes_total, uint8_t *payload,
+                             uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results) {
   if (!c || (n_sub && (!desc || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (payload_offsets) payload_offsets[0] = 0;
   if (n_sub == 0) return CABAC_HIP_OK;
   int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
   if (rc) return rc;
@@ -607,11 +614,13 @@ int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
     HIP_TRY(c, hipEventRecord(c->ev_in[k], c->s_in));
     hipStream_t ks = c->s_k[k % cabac_hip_ctx::kKernelStreams];
     HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_in[k], 0));
-    Bracket br = bracket_for(c, 0);
-    HIP_TRY(c, hipEventRecord(br.a, ks));
+    // (timed only through the profile ring: the ctx's single event pair would tie the chunk streams together)
+    const bool ring = !c->prof_ev.empty() && c->prof_n < c->prof_kind.size();
+    Bracket br = ring ? bracket_for(c, 0) : Bracket{nullptr, nullptr};
+    if (ring) HIP_TRY(c, hipEventRecord(br.a, ks));
     HIP_TRY(c, cabac::launch_encode(ks, c->enc_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_res + ch.s0, n_sub));
-    HIP_TRY(c, hipEventRecord(br.b, ks));
-    c->timed = (br.a == c->ev_start) && nc == 1;
+    if (ring) HIP_TRY(c, hipEventRecord(br.b, ks));
+    c->timed = false;
     // compaction: the coded substreams of the chunk back to back, so that they leave in ONE copy instead of one per
     // substream (the payload is ~0.1 B/bin; the slots are sized for the worst case)
     HIP_TRY(c, cabac::launch_assemble(ks, n_k, d_desc + ch.s0, d_res + ch.s0, d_slots, d_pay + ch.byte_lo,
@@ -627,26 +636,49 @@ int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
     HIP_TRY(c, hipEventSynchronize(c->ev_k[k]));
     const uint64_t n_pay = h_off[ch.s1 + k];
     pay_base[k + 1] = pay_base[k] + n_pay;
-    if ((rc = ensure_pinned_keep(c, 1, pay_base[k + 1], pay_base[k]))) return rc;
-    if (n_pay)
-      HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(c->h_pin[1]) + pay_base[k], d_pay + ch.byte_lo, n_pay, hipMemcpyDeviceToHost, c->s_out));
+    if (payload) {  // straight into the caller's payload (DMA if it is pinned, else through the bounce ring)
+      if (pay_base[k + 1] > payload_capacity) return fail(c, CABAC_HIP_ERR_INVALID, "payload_capacity too small");
+      if ((rc = d2h(c, payload + pay_base[k], d_pay + ch.byte_lo, n_pay, c->s_out))) return rc;
+    } else {
+      if ((rc = ensure_pinned_keep(c, 1, pay_base[k + 1], pay_base[k]))) return rc;
+      if (n_pay)
+        HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(c->h_pin[1]) + pay_base[k], d_pay + ch.byte_lo, n_pay, hipMemcpyDeviceToHost, c->s_out));
+    }
     HIP_TRY(c, hipEventRecord(c->ev_out[k], c->s_out));
   }
+  if (payload && (rc = d2h_drain(c))) return rc;
   int status = CABAC_HIP_OK;
   for (uint32_t k = 0; k < nc; k++) {
     const Chunk &ch = chunks[k];
     HIP_TRY(c, hipEventSynchronize(c->ev_out[k]));
-    const uint8_t *pay = static_cast<const uint8_t *>(c->h_pin[1]) + pay_base[k];
+    const uint8_t *pay = payload ? payload + pay_base[k] : static_cast<const uint8_t *>(c->h_pin[1]) + pay_base[k];
     const uint64_t *off = h_off + ch.s0 + k;
-    for (uint32_t s = ch.s0; s < ch.s1; s++) {  // into the caller's slots, as the reference's FIFOs hold them
+    for (uint32_t s = ch.s0; s < ch.s1; s++) {
       const uint64_t o = off[s - ch.s0], n = off[s - ch.s0 + 1] - o;
-      if (n && bytes) std::memcpy(bytes + desc[s].byte_offset, pay + o, n);
+      if (n && bytes) std::memcpy(bytes + desc[s].byte_offset, pay + o, n);  // into the caller's slots
+      if (payload_offsets) payload_offsets[s + 1] = pay_base[k] + o + n;
       results[s] = h_res[s];
       if (h_res[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
     }
   }
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
+}
+
+int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t n_records_total, uint8_t *bytes, uint64_t bytes_total,
+                           cabac_substream_result *results) {
+  return encode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, nullptr, 0, nullptr, results);
+}
+
+int cabac_hip_encode_batch_payload(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                   uint64_t n_records_total, uint8_t *payload, uint64_t payload_capacity,
+                                   uint64_t *payload_offsets, cabac_substream_result *results) {
+  if (!payload || !payload_offsets) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  uint64_t slots_end = 0;  // the device-side slots still follow the descriptors' byte_offset / byte_capacity
+  for (uint32_t s = 0; s < n_sub && desc; s++) slots_end = std::max<uint64_t>(slots_end, desc[s].byte_offset + desc[s].byte_capacity);
+  return encode_batch_impl(c, n_sub, desc, records, n_records_total, nullptr, slots_end, payload, payload_capacity,
+                           payload_offsets, results);
 }
 
 int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
@@ -719,11 +751,12 @@ int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
     HIP_TRY(c, hipEventRecord(c->ev_in[k], c->s_in));
     hipStream_t ks = c->s_k[k % cabac_hip_ctx::kKernelStreams];
     HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_in[k], 0));
-    Bracket br = bracket_for(c, 1);
-    HIP_TRY(c, hipEventRecord(br.a, ks));
+    const bool ring = !c->prof_ev.empty() && c->prof_n < c->prof_kind.size();
+    Bracket br = ring ? bracket_for(c, 1) : Bracket{nullptr, nullptr};
+    if (ring) HIP_TRY(c, hipEventRecord(br.a, ks));
     HIP_TRY(c, cabac::launch_decode(ks, c->dec_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_bins, d_res + ch.s0, n_sub));
-    HIP_TRY(c, hipEventRecord(br.b, ks));
-    c->timed = (br.a == c->ev_start) && nc == 1;
+    if (ring) HIP_TRY(c, hipEventRecord(br.b, ks));
+    c->timed = false;
     HIP_TRY(c, hipMemcpyAsync(h_res + ch.s0, d_res + ch.s0, n_k * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, ks));
     HIP_TRY(c, hipEventRecord(c->ev_k[k], ks));
     // the decoded bins of the chunk leave while the next chunk is decoded

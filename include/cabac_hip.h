@@ -303,8 +303,9 @@ int cabac_hip_host_is_pinned(const void *p, size_t bytes); /* 1 if [p, p + bytes
 
 /* ---- host-pointer entry points (synchronous) ---------------------------------------------------------------
  * The whole trip host -> device -> host.  A batch whose substreams lie in ascending order in records[] / bytes[] is cut
- * into chunks (about one per 1 024 substreams, at most 4); the H2D copy of chunk k+1, the kernel of chunk k and the D2H
- * copy of chunk k-1 run on three kinds of HIP streams of the ctx.  Pinned caller memory (see above) is DMA'd where it
+ * into chunks (two from 2 048 substreams and 16 M records up; the kernels' time is the length of the serial chains and does
+ * not shrink with the chunk, so more chunks cost more than their overlap gains); the H2D copy of chunk k+1, the kernel of
+ * chunk k and the D2H copy of chunk k-1 run on three kinds of HIP streams of the ctx.  Pinned caller memory (see above) is DMA'd where it
  * lies; pageable memory goes through a ring of pinned 4 MiB blocks inside the ctx, block n+1 being copied by the host
  * while block n is on the wire.  encode: the coded substreams are compacted on the device
  * (cabac_hip_assemble_device's kernels) and leave in one copy per chunk, then are placed at bytes + byte_offset.    */
@@ -314,6 +315,14 @@ int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
 int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
                            const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
                            uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
+/* The same encode with the output as a multiplexer wants it: the coded substreams back to back in descriptor order —
+ * what OutputBitstream::addSubstream (bit_stream.cpp:139-150) makes of byte-aligned substreams (code them with
+ * CABAC_SUB_ALIGN_RBSP) — in payload[0 .. payload_offsets[n_sub]), substream s at payload_offsets[s] ..
+ * payload_offsets[s + 1].  byte_offset / byte_capacity of the descriptors size the device-side slots only; no host pass
+ * over the output bytes (cabac_hip_encode_batch places every substream at its byte_offset: one memcpy per substream). */
+int cabac_hip_encode_batch_payload(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                                   const uint16_t *records, uint64_t n_records_total, uint8_t *payload,
+                                   uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results);
 
 /* Host-pointer form of cabac_hip_estimate_device (synchronous).  flags may be NULL;
  * returns CABAC_HIP_ERR_SUBSTREAM if any substream had a bad record.            */

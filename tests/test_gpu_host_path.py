@@ -42,6 +42,18 @@ def _check_against_oracle(hip, desc, records, total, pinned):
     for s in range(len(desc)):
         o, nb = int(desc["byte_offset"][s]), (int(res_o["n_bits"][s]) + 7) // 8
         assert np.array_equal(out_g[o:o + nb], out_o[o:o + nb]), s
+    # the payload form: the same substreams back to back (addSubstream order), no slots on the host
+    nbytes = np.minimum((res_o["n_bits"].astype(np.int64) + 7) // 8, desc["byte_capacity"].astype(np.int64))
+    pay = capi.PinnedArray((max(int(nbytes.sum()), 1),), np.uint8) if pinned else None
+    payload = pay.array if pinned else np.zeros(max(int(nbytes.sum()), 1), np.uint8)
+    offs, res_p = hip.encode_batch_payload(desc, h_rec, payload, check=False)
+    assert np.array_equal(res_p["n_bits"], res_o["n_bits"]) and np.array_equal(res_p["flags"], res_o["flags"])
+    assert np.array_equal(offs, np.concatenate([[0], np.cumsum(nbytes)]).astype(np.uint64))
+    for s in range(0, len(desc), 7):
+        o = int(desc["byte_offset"][s])
+        assert np.array_equal(payload[int(offs[s]): int(offs[s + 1])], out_o[o:o + int(nbytes[s])]), s
+    if pay is not None:
+        pay.close()
     dd = desc.copy()
     dd["byte_capacity"] = (res_o["n_bits"] + 7) // 8
     bins_g, rd = hip.decode_batch(dd, h_rec, h_out, check=False, bins=h_bins)
