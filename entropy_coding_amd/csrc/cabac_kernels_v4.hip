@@ -636,10 +636,12 @@ __device__ __forceinline__ void quad_rng_step(const QuadEncInfo &f, uint32_t &ra
   const uint32_t k = row_bcast<I>(f.k), c2 = row_bcast<I>(f.c2), lpsm = row_bcast<I>(f.lpsm);
   const uint32_t t = (__umul24((range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
   const uint32_t rm = range - t;
-  const uint32_t nl = (uint32_t)(__builtin_clz(t) - 23);  // getRenormBitsLPS; masked out when t == 0
-  const uint32_t nm = (rm >> 8) ^ 1u;                     // rm < 512: 1 iff rm < 256
-  const uint32_t nb = sel(lpsm, nl, nm);
-  range = sel(lpsm, t, rm) << nb;
+  // One renormalisation rule for both paths: the new range is the chosen sub-range shifted up to [256, 511].  LPS:
+  // clz(t) - 23 is getRenormBitsLPS (contexts.cpp:952-954; 7 for the terminate bin's t = 2).  MPS: rm >= 128 always
+  // (an LPS width is at most 15.5 / 32 of the range plus 4), so the shift is 1 iff rm < 256 (arith_codec.cpp:389-399).
+  const uint32_t x = sel(lpsm, t, rm);
+  const uint32_t nb = (uint32_t)(__builtin_clz(x) - 23);
+  range = x << nb;
   if (kAlign) range = sel(row_bcast<I>(f.alm), 256u, range);
   const uint32_t w = rm | (nb << 9);
   if (I & 1) cap.w[I >> 1] |= w << 16;
@@ -783,13 +785,19 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
+    // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
+    // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
+    uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
     mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
     __syncthreads();
     uint32_t slot = 1;
     for (uint32_t base = 0; base < max_n; base += 16) {
       const uint32_t r = next_rec;
-      next_rec = rec_safe[min(base + 32u + j, last_rec)];
+      next_rec = ahead1;
+      ahead1 = ahead2;
+      ahead2 = ahead3;
+      ahead3 = rec_safe[min(base + 80u + j, last_rec)];
       V5_TICK(t2);
       mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
       slot ^= 1u;
@@ -1052,14 +1060,19 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(e));
   const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
   const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
-  const uint32_t nl = (uint32_t)__builtin_clz(t) - 23u;          // getRenormBitsLPS; masked out when t == 0
-  uint32_t nm;  // MPS path: 1 iff rm < 256 (rm < 512): ngem & ~(rm >> 8) & 1 as ONE bit-op (hipcc splits off a v_not)
-  asm("v_bitop3_b32 %0, %1, %2, 1 bitop3:0x20" : "=v"(nm) : "v"(ngem), "v"(rm >> 8));
-  const uint32_t nsh = (gc & nl) | nm;
+  // One renormalisation rule for both paths: the chosen sub-range shifted up to [256, 511].  LPS (context bins only):
+  // clz(t) - 23 is getRenormBitsLPS.  Otherwise rm >= 128 (an LPS width is at most 15.5 / 32 of the range plus 4), so
+  // clz(rm) - 23 is 1 iff rm < 256 — the one-bit MPS renormalisation (arith_codec.cpp:60-73) — and 0 for a bypass bin
+  // (rm = range) and for the no-op steps past the end.
+  const uint32_t x = sel(gc, t, rm);
+  uint32_t nsh = (uint32_t)__builtin_clz(x) - 23u;
   uint32_t keep = ngem;
-  if (kSpecial) keep |= ~row_bcast<I>(f.ntrm);                   // terminate bin 1 leaves value untouched (:184-185)
+  if (kSpecial) {
+    keep |= ~row_bcast<I>(f.ntrm);                               // terminate bin 1 leaves value untouched (:184-185)
+    nsh &= ngem | row_bcast<I>(f.ntrm);                          // ... and does not renormalise
+  }
   w.hi = sel(keep, w.hi, e);
-  w.range = sel(gc, t, rm) << nsh;
+  w.range = x << nsh;
   if (kSpecial) {
     w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
     // After a terminate bin 1 nothing but finish() follows; keep range >= 256 so that the no-op steps past the

@@ -248,6 +248,7 @@ def _full_size_round_trip(hip, name, sample_stride):
     t_bytes = torch.zeros(total, dtype=torch.uint8, device="cuda")
     t_res = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
     t_bins = torch.zeros(len(records), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # the library launches on its own non-blocking stream: torch's fills must have landed first
     hip.encode_device(n, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_res.data_ptr())
     hip.synchronize()
     res = t_res.cpu().numpy().view(capi.RESULT_DTYPE)
@@ -255,6 +256,7 @@ def _full_size_round_trip(hip, name, sample_stride):
     ddesc = desc.copy(); ddesc["byte_capacity"] = (res["n_bits"] + 7) // 8
     t_ddesc = torch.from_numpy(ddesc.view(np.uint8)).cuda()
     t_res2 = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     hip.decode_device(n, t_ddesc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_bins.data_ptr(), t_res2.data_ptr())
     hip.synchronize()
     res2 = t_res2.cpu().numpy().view(capi.RESULT_DTYPE)
