@@ -1027,8 +1027,16 @@ constexpr uint32_t kRingStride = 66;  // 64 ring dwords + the mirror of dword 0 
 // Per-lane state: st_v, the packed context word of the lane's own record (0 for a non-context record).
 // kSpecial: the 16 records contain a terminate or an align record (rare) — the common variant leaves their
 // handling out.
+// The row-uniform fields of the 16 records of a step, one register per bin: the lanes compute them (lane I for bin I),
+// park them in LDS and every lane reads its row's sixteen back with four 16-byte reads per field — an LDS read of one
+// address by all lanes of a row IS the broadcast, and it replaces one v_mov_b32_dpp per bin and field (the consumers are
+// VOP3 / VOPC / SDWA encodings that cannot take a DPP operand themselves).
+struct QuadDecRow {
+  uint32_t c2[16], ctxm[16], srmul[16], ep[16], key[16];
+};
+
 template <int I, bool kSpecial>
-__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDecRow &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                               uint32_t &bits, QuadDec &w) {
   // Input check only every 4th bin (4 bins consume at most 24 bits): 16-bit units are appended while fewer than
   // 32 look-ahead bits are valid.  The question is asked here, the answer acted upon at the END of this step: a
@@ -1046,12 +1054,12 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   const uint32_t sum = (st & 0xffffu) + (st >> 16);  // the low half carries no rate bits here (see the kernel)
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
-  const uint32_t t = (__umul24(w.range >> 5, k) + row_bcast<I>(f.c2)) >> 1;
+  const uint32_t t = (__umul24(w.range >> 5, k) + u.c2[I]) >> 1;
   const uint32_t rm = w.range - t;
   // scaledRange at the window's scale, 2^22 (2^21 for a bypass bin) * rm.  As a multiplication on purpose: hipcc
   // folds the broadcast into the consumer, and v_lshlrev_b32 with DPP on its shift-amount operand returned
   // wrong results on gfx950 (bisected with the parity tests); v_mul_u32_u24 with DPP is fine.
-  const uint32_t sr = __umul24(rm, row_bcast<I>(f.srmul));
+  const uint32_t sr = __umul24(rm, u.srmul[I]);
   const uint32_t e = w.hi - sr;                                  // value - scaledRange; both are below 2^31
   // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0.  Through asm so that hipcc sees an opaque mask: written
   // as (int)e >> 31 it turns every use back into v_cmp + v_cndmask pairs, two instructions where a v_bfi /
@@ -1059,7 +1067,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   uint32_t ngem;
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(e));
   const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
-  const uint32_t gc = row_bcast<I>(f.ctxm) & ~ngem;
+  const uint32_t gc = u.ctxm[I] & ~ngem;
   // One renormalisation rule for both paths: the chosen sub-range shifted up to [256, 511].  LPS (context bins only):
   // clz(t) - 23 is getRenormBitsLPS.  Otherwise rm >= 128 (an LPS width is at most 15.5 / 32 of the range plus 4), so
   // clz(rm) - 23 is 1 iff rm < 256 — the one-bit MPS renormalisation (arith_codec.cpp:60-73) — and 0 for a bypass bin
@@ -1080,8 +1088,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
     w.range |= 256u & ~(ngem | row_bcast<I>(f.ntrm));
   }
   {
-    uint32_t tot;  // nsh + the bypass bit, the broadcast folded into the add (hipcc keeps a separate v_mov_b32_dpp)
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(tot) : "v"(f.ep), "v"(nsh), "n"(I));
+    const uint32_t tot = nsh + u.ep[I];  // the renormalisation shift and the bypass bit
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
@@ -1099,7 +1106,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
   uint32_t upd;  // both halves: rest + a * bin, the low half of `bin` feeding both lanes of the packed mad (op_sel_hi)
   asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(a_v), "v"(bin), "v"(rest));
   asm volatile("" : "+v"(upd));   // keep the update unconditional: hipcc would otherwise wrap it in an exec
-  st_v = (f.key == row_bcast<I>(f.key)) ? upd : st_v;
+  st_v = (f.key == u.key[I]) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
   if ((I & 3) == 0 && refill != 0) {
     quad_dec_check(w, refill2 != 0);
@@ -1107,9 +1114,9 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, uint32_t r0_
 }
 
 template <bool kSpecial>
-__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, const QuadDecRow &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                                uint32_t &bits, QuadDec &w) {
-#define QSTEP(I) quad_dec_step<I, kSpecial>(f, r0_v, a_v, st_v, bits, w)
+#define QSTEP(I) quad_dec_step<I, kSpecial>(f, u, r0_v, a_v, st_v, bits, w)
   QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
   QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
 #undef QSTEP
@@ -1129,6 +1136,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint8_t rate_all[W * kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t ring_all[W * kQuadSubs * kRingStride];
+  __shared__ uint32_t field_all[W][5][64];  // the record fields of a step on their way from lane I to the row (QuadDecRow)
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
@@ -1240,9 +1248,37 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     f.alm = aln_m;
     f.key = sel(ctxm, id, 0x200u + j);
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
+    QuadDecRow u;
+    {
+      // one wave writes and reads: LDS executes a wave's instructions in order, only the compiler has to keep it
+      field_all[wave][0][lane] = f.c2;
+      field_all[wave][1][lane] = f.ctxm;
+      field_all[wave][2][lane] = f.srmul;
+      field_all[wave][3][lane] = f.ep;
+      field_all[wave][4][lane] = f.key;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      auto fetch = [&](uint32_t which, uint32_t (&dst)[16]) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * 16u]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 v = p[q];
+          dst[4 * q] = v.x;
+          dst[4 * q + 1] = v.y;
+          dst[4 * q + 2] = v.z;
+          dst[4 * q + 3] = v.w;
+        }
+      };
+      fetch(0, u.c2);
+      fetch(1, u.ctxm);
+      fetch(2, u.srmul);
+      fetch(3, u.ep);
+      fetch(4, u.key);
+    }
     V5_TICK(t2);
-    if (special == 0) quad_dec_steps<false>(f, r0_v, a_v, st_v, bits, w);
-    else quad_dec_steps<true>(f, r0_v, a_v, st_v, bits, w);
+    if (special == 0) quad_dec_steps<false>(f, u, r0_v, a_v, st_v, bits, w);
+    else quad_dec_steps<true>(f, u, r0_v, a_v, st_v, bits, w);
     V5_TICK(t3);
     const uint32_t my_bin = (bits >> j) & 1u;
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
