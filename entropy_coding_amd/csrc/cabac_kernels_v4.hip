@@ -1088,6 +1088,8 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
     w.range |= 256u & ~(ngem | row_bcast<I>(f.ntrm));
   }
   {
+    // (as DPP operands of their VOP2 consumers srmul and ep would cost no move, but hipcc then pads every such consumer
+    // with s_nops — it applies the DPP read-after-write hazard to all of its operands: 122 s_nops per step against 38)
     const uint32_t tot = nsh + u.ep[I];  // the renormalisation shift and the bypass bit
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
     w.hi = (uint32_t)(v >> 32);
@@ -1203,21 +1205,65 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // The record ids of a step and the states of their contexts are fetched at the END of the step before (the records
   // were requested a whole step earlier; the context store has just been written back): the LDS round trip and the
   // dependent id / slot arithmetic are off the top of the step.
-  uint32_t cur_id, cur_stored, cur_rates;
+  uint32_t cur_id, cur_stored, cur_rates, cur_ctxm;
+  uint64_t cur_special;
+  QuadDecInfo f;
+  QuadDecRow u;
+  // Everything of a step that only depends on its records — the fields of the chain, parked in LDS and read back per row
+  // (QuadDecRow), the choice of the step variant — is prepared at the END of the step before, together with the context
+  // states (the store has just been written back): the LDS round trips are off the top of the step.
   auto fetch_contexts = [&](uint32_t base) {
     uint32_t r = next_rec;            // loaded one step ago
     asm volatile("" : "+v"(r));       // the wait for that load goes HERE
     const uint32_t actm = neg_mask(base + j - n);                  // ~0: a record of this substream
-    cur_id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);             // past the end: an id that is nothing
-    const uint32_t slot = min(cur_id, (uint32_t)kNumCtx);          // slot kNumCtx is the row's pad word
+    const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);  // past the end: an id that is nothing
+    cur_id = id;
+    const uint32_t slot = min(id, (uint32_t)kNumCtx);              // slot kNumCtx is the row's pad word
     cur_stored = rctx[slot];
     cur_rates = rrate[slot];
     next_rec = rec_safe[min(base + 16u + j, last_rec)];            // the records of the step after
+    // The fields as 0 / ~0 masks from arithmetic: a boolean expression would become a lane mask in SGPRs, and every scalar
+    // instruction combining such masks waits ~55 cycles for the vector compare.
+    const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
+    cur_special = __ballot((trm_m | aln_m) != 0);
+    const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);              // id < 379
+    cur_ctxm = ctxm;
+    bad |= actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
+    f.c2 = (8u & ctxm) | (4u & trm_m);
+    f.ep = neg_mask((id ^ CABAC_REC_EP) - 1u) & 1u;
+    f.srmul = 0x400000u >> f.ep;  // 2^(22 - ep)
+    f.ctxm = ctxm;
+    f.ntrm = ~trm_m;
+    f.alm = aln_m;
+    f.key = sel(ctxm, id, 0x200u + j);
+    // one wave writes and reads: LDS executes a wave's instructions in order, only the compiler has to keep it
+    field_all[wave][0][lane] = f.c2;
+    field_all[wave][1][lane] = f.ctxm;
+    field_all[wave][2][lane] = f.key;
+    field_all[wave][3][lane] = f.srmul;
+    field_all[wave][4][lane] = f.ep;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    auto fetch = [&](uint32_t which, uint32_t (&dst)[16]) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * 16u]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint4 v = p[q];
+        dst[4 * q] = v.x;
+        dst[4 * q + 1] = v.y;
+        dst[4 * q + 2] = v.z;
+        dst[4 * q + 3] = v.w;
+      }
+    };
+    fetch(0, u.c2);
+    fetch(1, u.ctxm);
+    fetch(2, u.key);
+    fetch(3, u.srmul);
+    fetch(4, u.ep);
   };
   fetch_contexts(0);
   for (uint32_t base = 0; base < max_n; base += 16) {
-    // The fields of this step's record, as 0 / ~0 masks from arithmetic: a boolean expression would become a lane
-    // mask in SGPRs, and every scalar instruction combining such masks waits ~55 cycles for the vector compare.
     V5_TICK(t0);
     V5_TICK(t1);
     // The bins of the previous step are stored only now, after the wait at the end of that step: loads and stores share
@@ -1226,56 +1272,16 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     if ((base & 48u) == 16u) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
     if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
     if ((base & 48u) == 0u) quad_dec_stage_load(w, j);    // steps 0, 4, 8, ...: request a block of input
-    const uint32_t actm = neg_mask(base + j - n);
-    const uint32_t id = cur_id;
-    const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
-    // asked first, needed last (the choice of the step variant): the branch finds the answer waiting
-    uint64_t special = __ballot((trm_m | aln_m) != 0);
+    const uint32_t id = cur_id, ctxm = cur_ctxm;
+    // asked long ago, needed now (the choice of the step variant): the branch finds the answer waiting
+    uint64_t special = cur_special;
     asm volatile("" : "+s"(special));
-    const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);              // id < 379
-    bad |= actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
     const uint32_t stored = cur_stored, rates = cur_rates;
     uint32_t st_v = stored & ctxm;
     const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
     const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
     const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
-    QuadDecInfo f;
-    f.c2 = (8u & ctxm) | (4u & trm_m);
-    f.ep = neg_mask((id ^ CABAC_REC_EP) - 1u) & 1u;
-    f.srmul = 0x400000u >> f.ep;  // 2^(22 - ep)
-    f.ctxm = ctxm;
-    f.ntrm = ~trm_m;
-    f.alm = aln_m;
-    f.key = sel(ctxm, id, 0x200u + j);
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
-    QuadDecRow u;
-    {
-      // one wave writes and reads: LDS executes a wave's instructions in order, only the compiler has to keep it
-      field_all[wave][0][lane] = f.c2;
-      field_all[wave][1][lane] = f.ctxm;
-      field_all[wave][2][lane] = f.srmul;
-      field_all[wave][3][lane] = f.ep;
-      field_all[wave][4][lane] = f.key;
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      auto fetch = [&](uint32_t which, uint32_t (&dst)[16]) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * 16u]);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint4 v = p[q];
-          dst[4 * q] = v.x;
-          dst[4 * q + 1] = v.y;
-          dst[4 * q + 2] = v.z;
-          dst[4 * q + 3] = v.w;
-        }
-      };
-      fetch(0, u.c2);
-      fetch(1, u.ctxm);
-      fetch(2, u.srmul);
-      fetch(3, u.ep);
-      fetch(4, u.key);
-    }
     V5_TICK(t2);
     if (special == 0) quad_dec_steps<false>(f, u, r0_v, a_v, st_v, bits, w);
     else quad_dec_steps<true>(f, u, r0_v, a_v, st_v, bits, w);
@@ -1284,7 +1290,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
-    fetch_contexts(base + 16u);                     // the next step's ids and context states
+    fetch_contexts(base + 16u);                     // the next step's ids, context states and record fields
     V5_TICK(t4);
     if (wave == 0) {
       V5_ADD(8, t0, t1);   // waiting for the record
