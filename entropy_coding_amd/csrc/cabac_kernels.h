@@ -25,6 +25,8 @@ hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substrea
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
+hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight = 0);
 

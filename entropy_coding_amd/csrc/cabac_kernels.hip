@@ -1159,6 +1159,7 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
   // auto (measured): the four-wave quad encoder (v6) has the shortest per-substream chain at every batch
   // size tried (C2: 10, C3: 256, C4: 4 096, C5: 8 192 substreams)
   if (kind == 6 || kind == 0) return launch_encode_v6(st, n_sub, desc, records, bytes, results, in_flight);
+  if (kind == 7) return launch_encode_v7(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 5) return launch_encode_v5(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 4) return launch_encode_v4(st, n_sub, desc, records, bytes, results);
   if (kind == 1) {
@@ -1181,7 +1182,7 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
   const int kind = variant & 0xff;
   // auto: the quad decoder has the shortest per-substream chain at every batch size measured (C2: 10,
   // C3: 256, C4: 4 096 substreams), because it never crosses between the scalar and vector pipes
-  if (kind == 4 || kind == 5 || kind == 6 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight);
+  if (kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight);
   if (kind == 1) {
     hipLaunchKernelGGL(decode_kernel_v1, dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
   } else if (kind != 2) {

@@ -939,6 +939,294 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// v7: the encoder with its serial parts turned by 90 degrees.
+//
+// v6 runs the range recurrence of FOUR substreams per chain wave, sixteen lanes per substream all computing the same
+// value, and a SIMD executes the four waves of a unit (~740 instructions per 16-bin step) — measured, v6 is bound by
+// that total, not by any one wave.  What needs the lanes of a row is only the context wave's work (which earlier bins of
+// the step share my context).  Everything downstream of it is a per-substream recurrence with nothing to share, so here
+// it runs one substream per LANE: per workgroup of S = 4U substreams
+//   U context waves   (v6's, four substreams each, lane = bin): per bin the fields of the chain and of the code value,
+//                      written to LDS field by field, [substream][bin];
+//   1 chain wave       lane = substream: reads its sixteen bins of each field with 16-byte reads and runs the range
+//                      recurrence — 9 instructions per bin for ALL substreams of the workgroup instead of 13 per four;
+//   1 output wave      lane = substream: the code value (low = (low << s) + term, 64-bit), its 16-bit units, the
+//                      delayed carry and the byte stores, exactly v4's per-row code, one step behind the chain.
+// One workgroup barrier per step; fields live in a ring of four steps (context waves one step ahead, output one behind).
+constexpr uint32_t kV7Pad = 20;  // words per substream and field: 16 bins + 4, so that neighbouring lanes' 16-byte reads spread over the banks
+enum : uint32_t { kV7K = 0, kV7C2, kV7Lpsm, kV7Lp9, kV7Ep, kV7Alm, kV7Fields };
+
+template <bool kAlign>
+__device__ __forceinline__ uint32_t lane_rng_step(uint32_t k, uint32_t c2, uint32_t lpsm, uint32_t alm, uint32_t &range) {
+  const uint32_t t = (__umul24((range >> 5) & 15u, k) + c2) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+  const uint32_t rm = range - t;
+  const uint32_t x = sel(lpsm, t, rm);                              // see quad_rng_step
+  const uint32_t nb = (uint32_t)(__builtin_clz(x) - 23);
+  range = x << nb;
+  if (kAlign) range = sel(alm, 256u, range);
+  return rm | (nb << 9);
+}
+
+__device__ __forceinline__ void lds_read4(const uint32_t *p, int q, uint32_t (&dst)[16]) {
+  const uint4 v = reinterpret_cast<const uint4 *>(p)[q];
+  dst[4 * q] = v.x;
+  dst[4 * q + 1] = v.y;
+  dst[4 * q + 2] = v.z;
+  dst[4 * q + 3] = v.w;
+}
+__device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&dst)[16]) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint4 v = q[i];
+    dst[4 * i] = v.x;
+    dst[4 * i + 1] = v.y;
+    dst[4 * i + 2] = v.z;
+    dst[4 * i + 3] = v.w;
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                                      const uint16_t *__restrict__ records,
+                                                                      uint8_t *__restrict__ bytes,
+                                                                      cabac_substream_result *__restrict__ results) {
+  constexpr uint32_t S = U * kQuadSubs;
+  __shared__ uint32_t ctx_all[S * kQuadCtxStride];
+  __shared__ __attribute__((aligned(16))) uint32_t fld[4][kV7Fields][S * kV7Pad];  // context waves -> chain / low wave
+  __shared__ __attribute__((aligned(16))) uint32_t wpost[2][64 * kV7Pad];           // chain -> low: rm | shift << 9 per bin
+  __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];  // low -> output (v5's posts)
+  __shared__ uint32_t fin_lo[S], fin_hi[S], fin_pend[S];
+  __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
+  __shared__ uint32_t special[4][U];
+  __shared__ uint32_t bad_rows[U];
+  __shared__ uint32_t wg_max_n;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves; then, for U = 4, two output
+  // waves, the chain wave, the low wave and the other two output waves — the chain and the low wave, the longest, each
+  // share their SIMD with one context wave only; for U = 1 context, chain, low, output on a SIMD each.
+  constexpr uint32_t kChainWave = U == 4 ? 6 : U, kLowWave = kChainWave + 1u;
+  const bool is_ctx = wave < (uint32_t)U, is_chain = wave == kChainWave, is_low = wave == kLowWave;
+  const bool is_out = !is_ctx && !is_chain && !is_low;
+  const bool quad = is_ctx || is_out;                       // lane = (row, bin / unit index) of one unit's four substreams
+  const uint32_t unit = is_ctx ? wave : (wave < kChainWave ? wave - (uint32_t)U : wave - (uint32_t)U - 2u);
+  const uint32_t row = lane >> 4, j = lane & 15u;
+  const uint32_t local = quad ? unit * kQuadSubs + row : min(lane, S - 1u);  // chain / low: lane = substream
+  const uint32_t sub = blockIdx.x * S + local;
+  const bool live = sub < n_sub && (quad || lane < S);
+  const cabac_substream_desc d = desc[sub < n_sub ? sub : 0];
+  const uint32_t n = sub < n_sub ? d.n_records : 0u;
+
+  if (threadIdx.x == 0) wg_max_n = 0;
+  __syncthreads();
+  atomicMax(&wg_max_n, n);
+  __syncthreads();
+  const uint32_t max_n = wg_max_n;
+  const uint32_t n_steps = (max_n + 15u) >> 4;
+  // every role: one barrier before the loop, one per step, two after it.  In iteration k the context waves prepare step
+  // k + 1, the chain wave runs step k, the low wave step k - 1, the output waves list the units of step k - 2 and store
+  // those of step k - 3.
+
+  if (is_ctx) {
+    const uint16_t *rec = records + d.rec_offset;
+    uint32_t *rctx = ctx_all + local * kQuadCtxStride;
+    quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
+    uint32_t bad = 0;
+    const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
+    const uint32_t last_rec = n != 0 ? n - 1u : 0u;
+    const uint32_t at = local * kV7Pad + j;
+    auto post = [&](uint32_t slot, uint32_t info) {
+      const uint32_t lpsm = bit_mask<9>(info), pem = bit_mask<11>(info);
+      fld[slot][kV7K][at] = info & 31u;
+      fld[slot][kV7C2][at] = (info >> 5) & 15u;
+      fld[slot][kV7Lpsm][at] = lpsm;
+      fld[slot][kV7Lp9][at] = (lpsm | pem) & 0x1ffu;   // the bin adds its MPS sub-range to low: LPS, or a bypass bin 1
+      fld[slot][kV7Ep][at] = (info >> 10) & 1u;
+      fld[slot][kV7Alm][at] = bit_mask<12>(info);
+      const uint64_t any = __ballot((info >> 12) != 0);
+      if (lane == 0) special[slot][unit] = any != 0 ? 1u : 0u;
+    };
+    const uint32_t cur_rec = rec_safe[min(j, last_rec)];
+    uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
+    uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
+    post(0, quad_phase_a(cur_rec, j < n, lane, row, rctx, bad));  // step 0
+    __syncthreads();
+    for (uint32_t k = 0; k < n_steps; k++) {
+      const uint32_t base = 16u * k;
+      const uint32_t r = next_rec;
+      next_rec = ahead1;
+      ahead1 = ahead2;
+      ahead2 = ahead3;
+      ahead3 = rec_safe[min(base + 80u + j, last_rec)];
+      V5_TICK(t0);
+      post((k + 1u) & 3u, quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad));
+      V5_TICK(t1);
+      __syncthreads();
+      V5_TICK(t2);
+      if (unit == 0) V5_ADD(0, t0, t1);
+      if (unit == 0) V5_ADD(1, t1, t2);
+    }
+    const uint64_t bad_mask = __ballot(bad != 0);
+    if (lane == 0) {
+      uint32_t rows = 0;
+      for (uint32_t q = 0; q < 4; q++) rows |= ((bad_mask >> (16u * q)) & 0xffffull) ? (1u << q) : 0u;
+      bad_rows[unit] = rows;
+    }
+    __syncthreads();
+    __syncthreads();
+  } else if (is_chain) {
+    // ---- chain wave: lane = substream ------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t range = 510;  // start(), arith_codec.cpp:329-337
+    __syncthreads();
+    for (uint32_t k = 0; k < n_steps; k++) {
+      V5_TICK(t0);
+      const uint32_t slot = k & 3u;
+      uint32_t kk[16], c2[16], lm[16], w[16];
+      // in bin order, so that the first four bins only wait for the first three reads
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        lds_read4(&fld[slot][kV7K][local * kV7Pad], q, kk);
+        lds_read4(&fld[slot][kV7C2][local * kV7Pad], q, c2);
+        lds_read4(&fld[slot][kV7Lpsm][local * kV7Pad], q, lm);
+      }
+      uint32_t any = 0;
+#pragma unroll
+      for (int q = 0; q < U; q++) any |= special[slot][q];
+      if (__builtin_amdgcn_readfirstlane((int)any) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = lane_rng_step<false>(kk[i], c2[i], lm[i], 0u, range);
+      } else {
+        uint32_t al[16];
+        lds_read16(&fld[slot][kV7Alm][local * kV7Pad], al);
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = lane_rng_step<true>(kk[i], c2[i], lm[i], al[i], range);
+      }
+      uint4 *dst = reinterpret_cast<uint4 *>(&wpost[k & 1u][lane * kV7Pad]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+      V5_TICK(t1);
+      __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(2, t0, t1);
+      V5_ADD(3, t1, t2);
+    }
+    __syncthreads();
+    __syncthreads();
+  } else if (is_low) {
+    // ---- low wave: lane = substream, the code value one step behind the chain; every 4th bin it posts (low, pend) and
+    // keeps only the pend % 16 bits that are not yet a whole unit (v5's chain wave did the same, see quad_enc_step) ----
+    uint64_t low = 0;
+    uint32_t pend = 0;
+    const uint32_t pu = local >> 2, pr = local & 3u;
+    auto low_step = [&](uint32_t k) {
+      const uint32_t slot = k & 3u;
+      uint32_t w[16], lp9[16], ep[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        lds_read4(&wpost[k & 1u][lane * kV7Pad], q, w);
+        lds_read4(&fld[slot][kV7Lp9][local * kV7Pad], q, lp9);
+        lds_read4(&fld[slot][kV7Ep][local * kV7Pad], q, ep);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        // low = (low + (LPS ? rm : 0)) << shift for a context / terminate bin, (low << 1) + (bin ? range : 0) for a bypass
+        // bin (arith_codec.cpp:389-399, :426-478); a bypass bin does not renormalise (nb = 0), so both are (rm << nb)
+        const uint32_t nb = w[i] >> 9;
+        const uint32_t term = (w[i] & lp9[i]) << nb;
+        const uint32_t sh = nb + ep[i];
+        low = (low << sh) + term;
+        pend += sh;
+        if ((i & 3) == 3) {
+          const uint32_t c = (uint32_t)(i >> 2) * kQuadSubs + pr;
+          if (lane < S) {
+            post_lo[pu][k & 1u][c] = (uint32_t)low;
+            post_hi[pu][k & 1u][c] = (uint32_t)(low >> 32);
+            post_pend[pu][k & 1u][c] = pend;
+          }
+          // whole units, and the carry above them, now belong to the post; without a whole unit nothing is cut
+          const uint32_t keep = pend & 15u;
+          const uint32_t width = pend >= 16u ? 9u + keep : 63u;
+          low &= ~(~0ull << width);
+          pend = keep;
+        }
+      }
+    };
+    __syncthreads();
+    for (uint32_t k = 0; k < n_steps; k++) {
+      V5_TICK(t0);
+      if (k != 0) low_step(k - 1u);
+      V5_TICK(t1);
+      __syncthreads();
+      V5_TICK(t2);
+      V5_ADD(4, t0, t1);
+      V5_ADD(5, t1, t2);
+    }
+    if (n_steps != 0) low_step(n_steps - 1u);
+    if (lane < S) {
+      fin_lo[local] = (uint32_t)low;
+      fin_hi[local] = (uint32_t)(low >> 32);
+      fin_pend[local] = pend;
+    }
+    __syncthreads();
+    __syncthreads();
+  } else {
+    // ---- output waves: v5's (quad_list_units / quad_emit_units), two steps behind the chain ----------------------
+    QuadEnc e;
+    e.low = 0;
+    e.range = 0;
+    e.pend = 0;
+    e.buf = 0;
+    e.nbuf = 0;
+    e.pos = 0;
+    e.dst = bytes + d.byte_offset;
+    e.cap = live ? d.byte_capacity : 0u;
+    const bool writer = live && j == 0;
+    uint32_t *list = unit_list[unit][row];
+    QuadUnits units;
+    units.m = 0;
+    units.odd_rows = 0;
+    units.store_lanes = 0;
+    bool listed = false;
+    auto list_step = [&](uint32_t k) {
+      units = quad_list_units(e, post_lo[unit][k & 1u], post_hi[unit][k & 1u], post_pend[unit][k & 1u], row, j, live, list);
+    };
+    __syncthreads();
+    for (uint32_t k = 0; k < n_steps; k++) {
+      V5_TICK(t0);
+      if (listed) quad_emit_units(e, units, j, list, writer);
+      listed = k >= 2u;
+      if (listed) list_step(k - 2u);
+      V5_TICK(t1);
+      __syncthreads();
+      V5_TICK(t2);
+      if (unit == 0) V5_ADD(6, t0, t1);
+      if (unit == 0) V5_ADD(7, t1, t2);
+    }
+    if (listed) quad_emit_units(e, units, j, list, writer);
+    if (n_steps >= 2u) {
+      list_step(n_steps - 2u);
+      quad_emit_units(e, units, j, list, writer);
+    }
+    __syncthreads();  // the low wave has posted its last step and what it still holds; bad_rows is written
+    if (n_steps != 0) {
+      list_step(n_steps - 1u);
+      quad_emit_units(e, units, j, list, writer);
+    }
+    e.low = ((uint64_t)fin_hi[local] << 32) | fin_lo[local];
+    e.pend = (int32_t)fin_pend[local];
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    if (writer) {
+      cabac_substream_result res;
+      res.n_bits = n_bits;
+      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
+      results[sub] = res;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // decode
 
 struct QuadDec {   // row-uniform values
@@ -1468,6 +1756,14 @@ hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substrea
   const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
   if (units_on_chip >= 1024u) hipLaunchKernelGGL(encode_kernel_v6<4>, dim3((units + 3) / 4), dim3(1024), 0, st, n_sub, desc, records, bytes, results);
   else hipLaunchKernelGGL(encode_kernel_v6<1>, dim3(units), dim3(256), 0, st, n_sub, desc, records, bytes, results);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
+  // sixteen substreams per workgroup once there are enough of them to give every CU one; four below that
+  if (max(n_sub, in_flight) >= 1024u) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3((n_sub + 15) / 16), dim3(640), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL(encode_kernel_v7<1>, dim3((n_sub + 3) / 4), dim3(256), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 

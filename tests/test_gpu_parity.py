@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 # kernel variants: 0 = auto, 3 = v3 phased wave (auto below 2 048 substreams), 4 = v4 quad, 5 = v5 three-wave
 # encoder, 6 = v6 three-wave encoder whose output wave rebuilds the code value (the chain wave only runs the range).  The superseded v1 (wave-serial) and v2 (lane-per-substream, 2 | L << 8) are never dispatched to by `auto`;
 # they stay selectable and get one parity pass of their own (test_legacy_variants_still_bit_exact), not the whole matrix.
-VARIANTS = {"auto": 0, "v3": 3, "v4": 4, "v5": 5, "v6": 6}
+VARIANTS = {"auto": 0, "v3": 3, "v4": 4, "v5": 5, "v6": 6, "v7": 7}
 LEGACY_VARIANTS = {"v1": 1, "v2_L4": 2 | (4 << 8)}
 
 

@@ -67,6 +67,20 @@ int main() {
       printf("v6 kernel %.3f ms; cycles per step, workgroup 0 (sum over its 4 units): context phase(a) %.0f barrier %.0f | chain %.0f post %.0f barrier %.0f | low %.0f barrier %.0f | emit %.0f barrier %.0f\n",
              vms, q[2] / g, q[3] / g, q[4] / g, q[6] / g, q[5] / g, q[1] / g, q[7] / g, q[0] / g, q[12] / g);
     }
+    for (int uu = 0; uu < 2; uu++) {  // the lane-serial encoder (v7): U = 4 (16 substreams per workgroup) and U = 1
+      unsigned long long z[16] = {};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), z, sizeof(z));
+      hipEvent_t c, d; (void)hipEventCreate(&c); (void)hipEventCreate(&d);
+      (void)hipEventRecord(c);
+      if (uu == 0) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3(n_sub / 16), dim3(640), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+      else hipLaunchKernelGGL(encode_kernel_v7<1>, dim3(n_sub / 4), dim3(256), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+      (void)hipEventRecord(d); (void)hipDeviceSynchronize();
+      float vms; (void)hipEventElapsedTime(&vms, c, d);
+      unsigned long long q[16];
+      (void)hipMemcpyFromSymbol(q, HIP_SYMBOL(g_v5_prof), sizeof(q));
+      printf("v7<%d> kernel %.3f ms; ticks per step, workgroup 0: context busy %.0f barrier %.0f | chain busy %.0f barrier %.0f | low busy %.0f barrier %.0f | output busy %.0f barrier %.0f\n",
+             uu == 0 ? 4 : 1, vms, q[0] / g, q[1] / g, q[2] / g, q[3] / g, q[4] / g, q[5] / g, q[6] / g, q[7] / g);
+    }
   }
   return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # encode variants side by side on the BASELINE workloads (GPU box): kernel times and the hash check
 for w in C2 C3 C4 C5; do
-  for v in 5 6; do
+  for v in 6 7; do
     python3 bench.py --workload $w --steps 5 --warmup 2 --enc-variant $v --no-residual --no-cpu-baseline --no-end-to-end 2>/dev/null > /tmp/vc.json
     python3 - "$w" "$v" <<'PY'
 import json, sys
