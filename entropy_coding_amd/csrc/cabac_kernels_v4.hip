@@ -747,16 +747,24 @@ __device__ __forceinline__ uint32_t quad_low_join(uint32_t v0, uint32_t v1, uint
 // code value and the emission in ONE output wave, that wave became the longest (its tree and its LDS round trips in a row:
 // 1.02 ms against v5's 0.98); apart, each fits beside the chain wave.  One workgroup barrier per 16-bin step; step k is
 // coded by the chain wave in iteration k, turned into units in iteration k + 1 and written out in iteration k + 2.
-template <int U>
+template <int U, int kSync>
 __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                             const uint16_t *__restrict__ records,
                                                             uint8_t *__restrict__ bytes,
                                                             cabac_substream_result *__restrict__ results) {
+  // kSync 16-bin steps per workgroup barrier.  Measured (tools/ubench_v5.hip, per-role probes): every role waits ~130 ns
+  // at each barrier on top of its own work, whoever arrives last.  With one unit per CU (small batches) two steps per
+  // barrier are 8 % faster (C2 0.81 -> 0.75 ms, C3 17.2 -> 15.9 ms); with four units per CU the SIMDs are the limit and
+  // one step per barrier is (C4 0.80 against 0.84 ms).  All hand-offs are rings of 2 kSync steps: in iteration i the
+  // context wave prepares steps kSync (i + 1) + h, the chain wave runs kSync i + h, the low wave turns kSync (i - 1) + h
+  // into units and the emit wave stores those of kSync (i - 2) + h (h < kSync).  Steps past the longest substream are
+  // no-ops (no active record, no shift, no unit).
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
-  __shared__ uint32_t mail_all[U][2][64];
-  __shared__ uint32_t quad_post[U][2][3][64];  // chain -> low: per lane (value low, value high, shift) of its four-bin segment
-  __shared__ uint32_t unit_list[U][2][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
-  __shared__ uint32_t unit_count[U][2][kQuadSubs];
+  constexpr uint32_t kRing = 2 * kSync;         // steps in flight between two neighbouring roles
+  __shared__ uint32_t mail_all[U][kRing][64];
+  __shared__ uint32_t quad_post[U][kRing][3][64];  // chain -> low: per lane (value low, value high, shift) of its four-bin segment
+  __shared__ uint32_t unit_list[U][kRing][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
+  __shared__ uint32_t unit_count[U][kRing][kQuadSubs];
   __shared__ uint32_t fin_acc[U][kQuadSubs], fin_rem[U][kQuadSubs];
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
@@ -773,10 +781,11 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   atomicMax(&wg_max_n, n);
   __syncthreads();
   const uint32_t max_n = wg_max_n;
-  // every role: one barrier before the loop, one per step, two after it
+  const uint32_t n_iters = (max_n + 16u * kSync - 1u) / (16u * kSync);
+  // every role: one barrier before the loop, one per iteration, two after it
 
   if (role == 0) {
-    // ---- context wave: exactly v5's -----------------------------------------------------------------
+    // ---- context wave ------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_CTX);
     const uint16_t *rec = records + d.rec_offset;
     uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
@@ -784,23 +793,28 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     uint32_t bad = 0;
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
-    const uint32_t cur_rec = rec_safe[min(j, last_rec)];
+    auto rec_of = [&](uint32_t step) { return (uint32_t)rec_safe[min(16u * step + j, last_rec)]; };
+    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a(r, 16u * step + j < n, lane, row, rctx, bad); };
     // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
     // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
-    uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
-    uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
-    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
+    uint32_t ahead[4];  // the records of the next four steps
+#pragma unroll
+    for (uint32_t h = 0; h < kSync; h++) phase(h, rec_of(h));
+#pragma unroll
+    for (uint32_t h = 0; h < 4; h++) ahead[h] = rec_of(kSync + h);
     __syncthreads();
-    uint32_t slot = 1;
-    for (uint32_t base = 0; base < max_n; base += 16) {
-      const uint32_t r = next_rec;
-      next_rec = ahead1;
-      ahead1 = ahead2;
-      ahead2 = ahead3;
-      ahead3 = rec_safe[min(base + 80u + j, last_rec)];
+    for (uint32_t it = 0; it < n_iters; it++) {
+      const uint32_t first = kSync * (it + 1u);
+      uint32_t fresh[kSync];
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) fresh[h] = rec_of(first + 4u + h);
       V5_TICK(t2);
-      mail[slot][lane] = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
-      slot ^= 1u;
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) phase(first + h, ahead[h]);
+#pragma unroll
+      for (uint32_t h = 0; h + kSync < 4; h++) ahead[h] = ahead[h + kSync];
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) ahead[4 - kSync + h] = fresh[h];
       V5_TICK(t3);
       __syncthreads();
       V5_TICK(t4);
@@ -817,40 +831,39 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
   } else if (role == 1) {
     // ---- chain wave: the range recurrence and nothing else -----------------------------------------------
-    // (v5's chain wave was the longest and got the issue priority; here the low and the emit wave are — few instructions,
-    // but chains of LDS round trips — so they go first whenever they are ready)
     __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_CHAIN);
     uint32_t range = 510;  // start(), arith_codec.cpp:329-337
     __syncthreads();
-    uint32_t slot = 0;
-    for (uint32_t base = 0; base < max_n; base += 16) {
-      const uint32_t info = mail[slot][lane];
-      const QuadEncInfo f = quad_unpack(info);
-      QuadRngCap cap;
+    for (uint32_t it = 0; it < n_iters; it++) {
       V5_TICK(t0);
-      if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
-      else quad_rng_steps<true>(f, range, cap);
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) {
+        const uint32_t slot = (kSync * it + h) & (kRing - 1u);
+        const uint32_t info = mail[slot][lane];
+        const QuadEncInfo f = quad_unpack(info);
+        QuadRngCap cap;
+        if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
+        else quad_rng_steps<true>(f, range, cap);
+        uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
+        quad_low_quads(cap, info, j, q0, q1, qs);
+        quad_post[unit][slot][0][lane] = q0;
+        quad_post[unit][slot][1][lane] = q1;
+        quad_post[unit][slot][2][lane] = qs;
+      }
       V5_TICK(t1);
-      uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
-      quad_low_quads(cap, info, j, q0, q1, qs);
-      quad_post[unit][slot][0][lane] = q0;
-      quad_post[unit][slot][1][lane] = q1;
-      quad_post[unit][slot][2][lane] = qs;
-      slot ^= 1u;
-      V5_TICK(t1b);
       __syncthreads();
       V5_TICK(t2);
-      if (unit == 0) V5_ADD(4, t0, t1);   // chain
-      if (unit == 0) V5_ADD(5, t1b, t2);  // waiting at the barrier
-      if (unit == 0) V5_ADD(6, t1, t1b);  // posting
+      if (unit == 0) V5_ADD(4, t0, t1);   // chain + posting
+      if (unit == 0) V5_ADD(5, t1, t2);   // waiting at the barrier
     }
     __syncthreads();
     __syncthreads();
   } else if (role == 2) {
-    // ---- low wave: in iteration k the code value of step k - 1 and its whole units -------------------------
+    // ---- low wave: the code values of the steps of the iteration before and their whole units ------------------
     __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_LOW);
     uint32_t acc = 0, rem = 0;  // row-uniform: the low 9 + rem bits of the code value (and a carry above), rem < 16
-    auto list_step = [&](uint32_t slot) {
+    auto list_step = [&](uint32_t step) {
+      const uint32_t slot = step & (kRing - 1u);
       uint32_t w[5];
       const uint32_t s_total = quad_low_join(quad_post[unit][slot][0][lane], quad_post[unit][slot][1][lane],
                                              quad_post[unit][slot][2][lane], acc, j, w);
@@ -868,18 +881,22 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       if (j == 0u) unit_count[unit][slot][row] = m;
     };
     __syncthreads();
-    uint32_t slot = 1;
-    for (uint32_t base = 0; base < max_n; base += 16) {
+    for (uint32_t it = 0; it < n_iters; it++) {
       V5_TICK(t0);
-      if (base != 0) list_step(slot);
-      slot ^= 1u;
+      if (it != 0) {
+#pragma unroll
+        for (uint32_t h = 0; h < kSync; h++) list_step(kSync * (it - 1u) + h);
+      }
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
       if (unit == 0) V5_ADD(1, t0, t1);   // low wave: code value + units
       if (unit == 0) V5_ADD(7, t1, t2);   // its barrier wait
     }
-    if (max_n != 0) list_step(slot);
+    if (n_iters != 0) {
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) list_step(kSync * (n_iters - 1u) + h);
+    }
     if (j == 0u) {
       fin_acc[unit][row] = acc;
       fin_rem[unit][row] = rem;
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
     __syncthreads();
   } else {
-    // ---- emit wave: in iteration k the units of step k - 2 -----------------------------------------------
+    // ---- emit wave: the units of the steps two iterations back ------------------------------------------------
     __builtin_amdgcn_s_setprio(CABAC_V6_PRIO_EMIT);
     QuadEnc e;
     e.low = 0;
@@ -899,7 +916,8 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     e.dst = bytes + d.byte_offset;
     e.cap = live ? d.byte_capacity : 0u;
     const bool writer = live && j == 0;
-    auto emit_step = [&](uint32_t slot) {
+    auto emit_step = [&](uint32_t step) {
+      const uint32_t slot = step & (kRing - 1u);
       const uint32_t *list = unit_list[unit][slot][row];
       QuadUnits u;
       u.m = unit_count[unit][slot][row];
@@ -910,21 +928,27 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
       quad_emit_units(e, u, j, list, writer);
     };
     __syncthreads();
-    uint32_t slot = 0;
-    for (uint32_t base = 0; base < max_n; base += 16) {
+    for (uint32_t it = 0; it < n_iters; it++) {
       V5_TICK(t0);
-      if (base >= 32u) emit_step(slot);
-      slot ^= 1u;
+      if (it >= 2u) {
+#pragma unroll
+        for (uint32_t h = 0; h < kSync; h++) emit_step(kSync * (it - 2u) + h);
+      }
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
       if (unit == 0) V5_ADD(0, t0, t1);   // emit wave
       if (unit == 0) V5_ADD(12, t1, t2);  // its barrier wait
     }
-    if (max_n > 16u) emit_step(slot);  // the step before the last
-    slot ^= 1u;
+    if (n_iters >= 2u) {  // listed in the last iteration
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) emit_step(kSync * (n_iters - 2u) + h);
+    }
     __syncthreads();
-    if (max_n != 0) emit_step(slot);   // the last step
+    if (n_iters != 0) {   // listed after the loop
+#pragma unroll
+      for (uint32_t h = 0; h < kSync; h++) emit_step(kSync * (n_iters - 1u) + h);
+    }
     __syncthreads();
     e.low = fin_acc[unit][row];
     e.pend = (int32_t)fin_rem[unit][row];
@@ -1754,8 +1778,8 @@ hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substrea
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
   const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
-  if (units_on_chip >= 1024u) hipLaunchKernelGGL(encode_kernel_v6<4>, dim3((units + 3) / 4), dim3(1024), 0, st, n_sub, desc, records, bytes, results);
-  else hipLaunchKernelGGL(encode_kernel_v6<1>, dim3(units), dim3(256), 0, st, n_sub, desc, records, bytes, results);
+  if (units_on_chip >= 1024u) hipLaunchKernelGGL((encode_kernel_v6<4, 1>), dim3((units + 3) / 4), dim3(1024), 0, st, n_sub, desc, records, bytes, results);
+  else hipLaunchKernelGGL((encode_kernel_v6<1, 2>), dim3(units), dim3(256), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 

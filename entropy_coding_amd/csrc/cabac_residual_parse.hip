@@ -167,10 +167,13 @@ __device__ __forceinline__ uint32_t pd_bin(PDec &d, uint4 *ctx, uint32_t slot) {
   const uint32_t ev = d.hi - (rm << 22);                        // value - scaledRange
   const bool mps = (int32_t)ev < 0;
   const uint32_t bin = (mps ? sx : ~sx) & 1u;
-  // renormalisation: LPS by getRenormBitsLPS = clz(t) - 23, MPS by one bit iff rm < 256 (rm < 512)
-  const uint32_t nsh = mps ? (rm >> 8) ^ 1u : (uint32_t)__builtin_clz(t) - 23u;
-  d.hi = mps ? d.hi : ev;
-  d.range = (mps ? rm : t) << nsh;
+  // renormalisation, one rule for both paths: the chosen sub-range shifted up to [256, 511] — LPS by getRenormBitsLPS =
+  // clz(t) - 23; MPS by one bit iff rm < 256, which is clz(rm) - 23 because rm >= 128 (an LPS width is at most 15.5 / 32
+  // of the range plus 4)
+  const uint32_t x = mps ? rm : t;
+  const uint32_t nsh = (uint32_t)__builtin_clz(x) - 23u;
+  d.hi = min(d.hi, ev);   // ev wraps above 2^31 exactly when value < scaledRange
+  d.range = x << nsh;
   const uint64_t v = (((uint64_t)d.hi << 32) | d.lo) << nsh;
   d.hi = (uint32_t)(v >> 32);
   d.lo = (uint32_t)v;

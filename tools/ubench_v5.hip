@@ -59,7 +59,7 @@ int main() {
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), z, sizeof(z));
       hipEvent_t c, d; (void)hipEventCreate(&c); (void)hipEventCreate(&d);
       (void)hipEventRecord(c);
-      hipLaunchKernelGGL(encode_kernel_v6<4>, dim3(n_sub / 16), dim3(1024), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+      hipLaunchKernelGGL((encode_kernel_v6<4, 1>), dim3(n_sub / 16), dim3(1024), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
       (void)hipEventRecord(d); (void)hipDeviceSynchronize();
       float vms; (void)hipEventElapsedTime(&vms, c, d);
       unsigned long long q[16];
