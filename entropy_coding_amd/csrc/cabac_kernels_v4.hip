@@ -1448,13 +1448,14 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // decode keeps the two window sizes of a context (they never change) apart from its state word, whose low
   // five bits are then zero: state() is one SDWA add of the two halves, without masking
   __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
-  __shared__ uint8_t rate_all[W * kQuadSubs * kQuadCtxStride];
+  // what a record id means for the chain, looked up instead of computed (one 32-byte entry per id, the same for every
+  // substream: the window sizes of a context do not depend on QP or slice type): {c2, srmul, ctxm, ep | r0_v, a_v, ntrm, alm}
+  __shared__ __attribute__((aligned(16))) uint32_t rec_tab[512][8];
   __shared__ uint32_t ring_all[W * kQuadSubs * kRingStride];
   __shared__ uint32_t field_all[W][5][64];  // the record fields of a step on their way from lane I to the row (QuadDecRow)
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
   const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
-  uint8_t *rrate = rate_all + (wave * kQuadSubs + row) * kQuadCtxStride;
   const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -1468,8 +1469,27 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16) {
       const uint32_t packed = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
       rctx[k] = packed & ~31u;
-      rrate[k] = (uint8_t)(packed & 31u);
     }
+  }
+  for (uint32_t id = threadIdx.x; id < 512u; id += 64u * W) {
+    const uint32_t ctxm = id < (uint32_t)kNumCtx ? ~0u : 0u;
+    const uint32_t trm_m = id == CABAC_REC_TRM ? ~0u : 0u, aln_m = id == CABAC_REC_ALIGN ? ~0u : 0u;
+    const uint32_t ep = id == CABAC_REC_EP ? 1u : 0u;
+    uint32_t r0_v = 0, a_v = 0;
+    if (ctxm) {
+      const uint32_t rates = ctx2_init(0, c_init_tables[id], c_init_tables[3 * kNumCtx + id]) & 31u;
+      const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
+      a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
+      r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
+    }
+    rec_tab[id][0] = (8u & ctxm) | (4u & trm_m);  // 2 * constant term of the LPS width
+    rec_tab[id][1] = 0x400000u >> ep;             // 2^(22 - ep)
+    rec_tab[id][2] = ctxm;
+    rec_tab[id][3] = ep;
+    rec_tab[id][4] = r0_v;
+    rec_tab[id][5] = a_v;
+    rec_tab[id][6] = ~trm_m;
+    rec_tab[id][7] = aln_m;
   }
   __syncthreads();
 
@@ -1512,41 +1532,44 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   const uint32_t max_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_wave);
   const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
   const uint32_t last_rec = n != 0 ? n - 1u : 0u;
-  uint32_t next_rec = rec_safe[min(j, last_rec)];
+  // Records are requested three steps ahead.  What a step needs besides the bins — the meaning of its record ids (rec_tab),
+  // the fields of the chain parked in LDS and read back per row (QuadDecRow), the choice of the step variant, the context
+  // states — is prepared in two stages off the top of the step: the table rows are requested at the START of the step
+  // before (they arrive during its chain), the rest at its END (the context store has just been written back).
+  uint32_t rec1 = rec_safe[min(j, last_rec)], rec2 = rec_safe[min(16u + j, last_rec)], rec3 = rec_safe[min(32u + j, last_rec)];
   uint32_t prev_bin = 0, prev_idx = ~0u;  // the bins of the previous step, not yet stored
-  // The record ids of a step and the states of their contexts are fetched at the END of the step before (the records
-  // were requested a whole step earlier; the context store has just been written back): the LDS round trip and the
-  // dependent id / slot arithmetic are off the top of the step.
-  uint32_t cur_id, cur_stored, cur_rates, cur_ctxm;
+  uint32_t nxt_id, nxt_actm;
+  uint4 nxt_a, nxt_b;
+  auto request = [&](uint32_t base) {  // stage 1 for the step at `base`: its ids and their table rows
+    uint32_t r = rec1;               // loaded two steps ago
+    rec1 = rec2;
+    rec2 = rec3;
+    rec3 = rec_safe[min(base + 48u + j, last_rec)];
+    nxt_actm = neg_mask(base + j - n);                              // ~0: a record of this substream
+    nxt_id = sel(nxt_actm, r & CABAC_REC_ID_MASK, 0x1f0u);         // past the end: an id that is nothing
+    const uint4 *row4 = reinterpret_cast<const uint4 *>(rec_tab[nxt_id]);
+    nxt_a = row4[0];
+    nxt_b = row4[1];
+  };
+  uint32_t cur_id, cur_stored, cur_ctxm, cur_r0v, cur_av;
   uint64_t cur_special;
   QuadDecInfo f;
   QuadDecRow u;
-  // Everything of a step that only depends on its records — the fields of the chain, parked in LDS and read back per row
-  // (QuadDecRow), the choice of the step variant — is prepared at the END of the step before, together with the context
-  // states (the store has just been written back): the LDS round trips are off the top of the step.
-  auto fetch_contexts = [&](uint32_t base) {
-    uint32_t r = next_rec;            // loaded one step ago
-    asm volatile("" : "+v"(r));       // the wait for that load goes HERE
-    const uint32_t actm = neg_mask(base + j - n);                  // ~0: a record of this substream
-    const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, 0x1f0u);  // past the end: an id that is nothing
+  auto prepare = [&]() {              // stage 2 for the step requested last
+    const uint32_t id = nxt_id, ctxm = nxt_a.z;
     cur_id = id;
-    const uint32_t slot = min(id, (uint32_t)kNumCtx);              // slot kNumCtx is the row's pad word
-    cur_stored = rctx[slot];
-    cur_rates = rrate[slot];
-    next_rec = rec_safe[min(base + 16u + j, last_rec)];            // the records of the step after
-    // The fields as 0 / ~0 masks from arithmetic: a boolean expression would become a lane mask in SGPRs, and every scalar
-    // instruction combining such masks waits ~55 cycles for the vector compare.
-    const uint32_t trm_m = neg_mask((id ^ CABAC_REC_TRM) - 1u), aln_m = neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
-    cur_special = __ballot((trm_m | aln_m) != 0);
-    const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);              // id < 379
     cur_ctxm = ctxm;
-    bad |= actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
-    f.c2 = (8u & ctxm) | (4u & trm_m);
-    f.ep = neg_mask((id ^ CABAC_REC_EP) - 1u) & 1u;
-    f.srmul = 0x400000u >> f.ep;  // 2^(22 - ep)
+    cur_r0v = nxt_b.x;
+    cur_av = nxt_b.y;
+    cur_stored = rctx[min(id, (uint32_t)kNumCtx)];                 // slot kNumCtx is the row's pad word
+    f.c2 = nxt_a.x;
+    f.srmul = nxt_a.y;
     f.ctxm = ctxm;
-    f.ntrm = ~trm_m;
-    f.alm = aln_m;
+    f.ep = nxt_a.w;
+    f.ntrm = nxt_b.z;
+    f.alm = nxt_b.w;
+    cur_special = __ballot((~f.ntrm | f.alm) != 0);
+    bad |= nxt_actm & ~ctxm & neg_mask(id - CABAC_REC_ALIGN);
     f.key = sel(ctxm, id, 0x200u + j);
     // one wave writes and reads: LDS executes a wave's instructions in order, only the compiler has to keep it
     field_all[wave][0][lane] = f.c2;
@@ -1574,7 +1597,8 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     fetch(3, u.srmul);
     fetch(4, u.ep);
   };
-  fetch_contexts(0);
+  request(0);
+  prepare();
   for (uint32_t base = 0; base < max_n; base += 16) {
     V5_TICK(t0);
     V5_TICK(t1);
@@ -1588,11 +1612,9 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     // asked long ago, needed now (the choice of the step variant): the branch finds the answer waiting
     uint64_t special = cur_special;
     asm volatile("" : "+s"(special));
-    const uint32_t stored = cur_stored, rates = cur_rates;
-    uint32_t st_v = stored & ctxm;
-    const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
-    const uint32_t a_v = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
-    const uint32_t r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
+    uint32_t st_v = cur_stored & ctxm;
+    const uint32_t a_v = cur_av, r0_v = cur_r0v;
+    request(base + 16u);                                  // the ids and table rows of the next step
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
     V5_TICK(t2);
     if (special == 0) quad_dec_steps<false>(f, u, r0_v, a_v, st_v, bits, w);
@@ -1602,7 +1624,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
-    fetch_contexts(base + 16u);                     // the next step's ids, context states and record fields
+    prepare();                                      // the next step's context states and record fields
     V5_TICK(t4);
     if (wave == 0) {
       V5_ADD(8, t0, t1);   // waiting for the record
