@@ -115,7 +115,10 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 // ---------------------------------------------------------------------------------------------------------------
 // arithmetic decoder
 
-struct PDec {
+template <bool kS>
+struct PDecT {
+  // kS: this wave keeps the decoder on the SCALAR unit (see pd_bin)
+  static constexpr bool kScalar = kS;
   uint32_t hi, lo;   // window (wave-uniform, kept in vector registers): value in bits 62..47
   uint32_t range;    //   "
   int32_t look;      //   "   valid look-ahead bits below bit 47
@@ -125,7 +128,8 @@ struct PDec {
   uint32_t cap, last_dword, lane;
 };
 
-__device__ __forceinline__ uint32_t pd_load_block(const PDec &d, uint32_t blk) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_load_block(const D &d, uint32_t blk) {
   const uint32_t off = blk * 256u + 4u * d.lane;
   const uint32_t w = *reinterpret_cast<const uint32_t *>(d.src_safe + min(off, d.last_dword));
   return off < d.cap ? __builtin_bswap32(w) : 0u;  // past the end of the substream the window is fed zeros
@@ -133,7 +137,8 @@ __device__ __forceinline__ uint32_t pd_load_block(const PDec &d, uint32_t blk) {
 
 // Append 16-bit units while fewer than 32 look-ahead bits are valid (at most two: look >= 0 here).  Afterwards 32 bits
 // can be consumed before the next check.
-__device__ __forceinline__ void pd_check(PDec &d) {
+template <class D>
+__device__ __forceinline__ void pd_check(D &d) {
   int32_t look = (int32_t)rfl((uint32_t)d.look);
   while (__builtin_expect(look < 32, 0)) {
     const uint32_t dw = rl(d.in_cur, (d.rp >> 2) & 63u);
@@ -155,10 +160,16 @@ __device__ __forceinline__ void pd_check(PDec &d) {
 // ctx[slot] = {s0 | s1 << 16 (rate bits cleared), shift0 | shift1 << 16, add0 | add1 << 16, -}.  Branch-free: the one
 // data-dependent decision of the walk is taken on the returned bin.  The walk is bound by instruction issue, so this is
 // written for count: 31 vector instructions, two LDS accesses and the one v_readfirstlane.
-__device__ __forceinline__ uint32_t pd_bin(PDec &d, uint4 *ctx, uint32_t slot) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_bin(D &d, uint4 *ctx, uint32_t slot) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   const uint4 e = ctx[slot];
-  const uint32_t st = e.x;
+  // A SIMD has a vector and a scalar pipe that run side by side — for DIFFERENT waves (tools/ubench_mix.hip: four waves of
+  // vector code 7.9 ns per instruction and wave, four of scalar code 7.1, two and two 4.2).  The decision arithmetic of a bin
+  // is the same ~20 instructions on wave-uniform values either way, so every other wave of a workgroup runs it on the
+  // scalar pipe: the state word crosses over first (one v_readfirstlane) and hipcc, seeing uniform values, picks s_
+  // instructions; the other waves keep it in vector registers and only the decoded bin crosses.
+  const uint32_t st = D::kScalar ? rfl(e.x) : e.x;
   const uint32_t sum = (st & 0xffffu) + (st >> 16);
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
@@ -178,18 +189,20 @@ __device__ __forceinline__ uint32_t pd_bin(PDec &d, uint4 *ctx, uint32_t slot) {
   d.hi = (uint32_t)(v >> 32);
   d.lo = (uint32_t)v;
   d.look -= (int32_t)nsh;
-  // update(bin) on both 15-bit estimators at once
-  const u16x2 st2 = __builtin_bit_cast(u16x2, st);
+  // update(bin) on both 15-bit estimators at once (vector pipe in both kinds of wave: there is no packed scalar math)
+  const u16x2 st2 = __builtin_bit_cast(u16x2, e.x);
   const u16x2 dlt2 = (st2 >> __builtin_bit_cast(u16x2, e.y)) & __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
   const uint32_t rest = __builtin_bit_cast(uint32_t, (u16x2)(st2 - dlt2));
   uint32_t upd;
-  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(e.z), "v"(bin), "v"(rest));
+  if (D::kScalar) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(e.z), "s"(bin), "v"(rest));
+  else asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(e.z), "v"(bin), "v"(rest));
   ctx[slot].x = upd;
-  return rfl(bin);
+  return D::kScalar ? bin : rfl(bin);
 }
 
 // decodeBinEP, arith_codec.cpp:100-114: the doubling of value is folded into the comparison (against scaledRange / 2)
-__device__ __forceinline__ uint32_t pd_ep(PDec &d) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_ep(D &d) {
   const uint32_t ev = d.hi - (d.range << 21);
   const uint32_t ngem = (uint32_t)((int32_t)ev >> 31);
   d.hi = (d.hi & ngem) | (ev & ~ngem);
@@ -202,7 +215,8 @@ __device__ __forceinline__ uint32_t pd_ep(PDec &d) {
 
 // The next n (1..15) bypass bins as one number, MSB first, WITHOUT consuming them: they are the quotient of the value
 // extended by n stream bits by the scaled range (what n rounds of decodeBinEP compute bit by bit).  look >= n.
-__device__ __forceinline__ uint32_t pd_ep_peek(const PDec &d, uint32_t n) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_ep_peek(const D &d, uint32_t n) {
   // value (16 bits) and n more bits, over 128 * range: floor(floor(V / 128) / range), V / 128 < 2^24 exactly a float
   const uint32_t a = d.hi >> (22u - n);
   const float fr = (float)d.range;
@@ -214,7 +228,8 @@ __device__ __forceinline__ uint32_t pd_ep_peek(const PDec &d, uint32_t n) {
 }
 
 // consume k of the bins just peeked (bins = their values, MSB first)
-__device__ __forceinline__ void pd_ep_take(PDec &d, uint32_t bins, uint32_t k) {
+template <class D>
+__device__ __forceinline__ void pd_ep_take(D &d, uint32_t bins, uint32_t k) {
   const uint64_t v = (((uint64_t)d.hi << 32) | d.lo) << k;
   d.hi = (uint32_t)(v >> 32) - ((bins * d.range) << 22);
   d.lo = (uint32_t)v;
@@ -222,7 +237,8 @@ __device__ __forceinline__ void pd_ep_take(PDec &d, uint32_t bins, uint32_t k) {
 }
 
 // decodeBinsEP(n), n <= 32 (arith_codec.cpp:116-151)
-__device__ __forceinline__ uint32_t pd_bins_ep(PDec &d, uint32_t n) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_bins_ep(D &d, uint32_t n) {
   uint32_t out = 0;
   while (n != 0u) {
     const uint32_t k = n < 15u ? n : 15u;
@@ -236,7 +252,8 @@ __device__ __forceinline__ uint32_t pd_bins_ep(PDec &d, uint32_t n) {
 }
 
 // decodeRemAbsEP with cutoff 5 (arith_codec.cpp:153-179): unary prefix of at most 32 - maxLog2 ones, then the suffix
-__device__ __forceinline__ uint32_t pd_rem_abs(PDec &d, uint32_t rice, uint32_t max_log2) {
+template <class D>
+__device__ __forceinline__ uint32_t pd_rem_abs(D &d, uint32_t rice, uint32_t max_log2) {
   const uint32_t cutoff = 5u, max_prefix = 32u - max_log2;
   uint32_t prefix = 0;
   for (;;) {
@@ -307,7 +324,8 @@ __device__ __forceinline__ int32_t blk_val(const int32_t *blk, const BlockGeom &
 __device__ __forceinline__ uint32_t sig_set_base(uint32_t set) { return (uint32_t)((0x8E827A6E665Aull >> (8u * set)) & 0xffu); }
 
 // ---- regular residual coding: one block (after ts_flag) -----------------------------------------------------------
-__device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
+template <class D>
+__device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
                                                   uint32_t lane) {
   const uint32_t chroma = g.chroma, j = lane & 15u;
   PP_TICK(p0);
@@ -511,7 +529,8 @@ __device__ __forceinline__ uint32_t parse_regular(PDec &d, uint4 *ctx, int32_t *
 }
 
 // ---- transform-skip residual coding: one block (cabac_reader.cpp:3130-3339) ------------------------------------------
-__device__ __forceinline__ void parse_ts(PDec &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g, uint32_t lane) {
+template <class D>
+__device__ __forceinline__ void parse_ts(D &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g, uint32_t lane) {
   const uint32_t j = lane & 15u;
   const bool bdpcm = (g.fl & CABAC_TU_BDPCM) != 0u;
   const uint32_t ip = tab.in_cg[g.cgw_l2][g.cgh_l2][j];
@@ -664,7 +683,15 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
   __syncthreads();
   if (!live) return;
 
-  PDec d;
+  // every other wave SLOT of a SIMD keeps its decoder on the scalar pipe (pd_bin): whatever the placement, the waves that
+  // share a SIMD split about evenly
+#ifndef CABAC_PARSE_SCALAR_WAVES
+#define CABAC_PARSE_SCALAR_WAVES 0   // 0: none, 1: every other wave slot, 2: all.  Measured on the bench tiles: 6.30 / 6.73 / - ms
+#endif
+  const bool scalar_wave = CABAC_PARSE_SCALAR_WAVES == 2 ||
+                           (CABAC_PARSE_SCALAR_WAVES == 1 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u) != 0u);   // HW_ID.wave_id[3:0]
+  auto walk = [&](auto kind) {
+  PDecT<decltype(kind)::value> d;
   d.lane = lane;
   d.cap = dsc.byte_capacity;
   const uint8_t *src = bytes + dsc.byte_offset;
@@ -781,6 +808,9 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     r.flags = flags_out;
     results[sub] = r;
   }
+  };
+  if (scalar_wave) walk(std::true_type{});
+  else walk(std::false_type{});
 }
 
 #ifdef CABAC_PARSE_PROFILE

@@ -54,3 +54,12 @@ for c in sorted(set(cnt)):
     print("  CUs with %d waves: mean wave time %.0f" % (c, dur[sel].mean()))
 for x in range(8):
     print("  xcc %d: waves %d mean %.0f" % (x, (xcc == x).sum(), dur[xcc == x].mean() if (xcc == x).any() else 0))
+# when does each SIMD / CU run dry?  (the kernel ends with the last one; s_memtime has its own base on every XCC, so
+# times are taken relative to the first start on the same SIMD / CU)
+valid = w[:, 1] > 0
+sraw, eraw = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64)
+e_simd = np.array([eraw[valid & (key_simd == k)].max() - sraw[valid & (key_simd == k)].min() for k in us])
+e_cu = np.array([eraw[valid & (key_cu == k)].max() - sraw[valid & (key_cu == k)].min() for k in ucu])
+print("a SIMD is busy for: min %d  mean %.0f  max %d ticks" % (e_simd.min(), e_simd.mean(), e_simd.max()))
+print("a CU is busy for:   min %d  mean %.0f  max %d ticks" % (e_cu.min(), e_cu.mean(), e_cu.max()))
+print("wave durations: percentiles 0/25/50/75/100:", np.percentile((eraw - sraw)[valid], [0, 25, 50, 75, 100]).astype(np.int64))
