@@ -1,5 +1,6 @@
 """ctypes binding of include/cabac_hip.h — test/bench plumbing; the product is the shared library."""
 import ctypes
+import sys
 import os
 
 import numpy as np
@@ -135,8 +136,11 @@ class PinnedArray:
             self._p = None
 
     def __del__(self):
+        # not while the interpreter is shutting down: the HIP runtime (torch's, ours) may already be unloading then, and a
+        # stream / event / pinned-memory release into a half-torn-down runtime can abort the process; the OS reclaims it all
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
@@ -170,8 +174,11 @@ class CabacHip:
             self.h = None
 
     def __del__(self):
+        # not while the interpreter is shutting down: the HIP runtime (torch's, ours) may already be unloading then, and a
+        # stream / event / pinned-memory release into a half-torn-down runtime can abort the process; the OS reclaims it all
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
