@@ -58,3 +58,35 @@ json.dump(out, open(os.path.join(dst, "pmc_traffic_" + tag + ".json"), "w"), ind
 for k, rows in kernels.items():
     print("%-44s launches %3d  last: fetch x2 %.1f MB  write %.1f MB  total %.1f MB" %
           (k, len(rows), 2 * rows[-1]["FETCH_SIZE_KiB_raw"] / 1024 * 1.048576, rows[-1]["WRITE_SIZE_KiB"] / 1024 * 1.048576, rows[-1]["hbm_bytes"] / 1e6))
+
+# bench.py's `traffic` fields read profiles/pmc_traffic.json: refresh the C4 entries of the kernels measured in this run
+path = os.path.join(dst, "pmc_traffic.json")
+t = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
+c4 = t.setdefault("workloads", {}).setdefault("C4", {})
+
+
+def entry(rows):
+    return {"FETCH_SIZE_KiB_raw": rows["FETCH_SIZE_KiB_raw"], "WRITE_SIZE_KiB": rows["WRITE_SIZE_KiB"], "hbm_bytes_per_launch": rows["hbm_bytes"],
+            "measured": tag}
+
+
+def first(prefix):
+    for k, rows in kernels.items():
+        if k.startswith(prefix) and rows:
+            return rows[0]      # the first launch is the C4 batch of the timed region (later ones: the residual leg's substreams)
+    return None
+
+
+for name, prefix in (("encode_kernel_v6", "encode_kernel_v6"), ("decode_kernel_v4", "decode_kernel_v4"), ("estimate_kernel", "estimate_kernel"),
+                     ("residual_parse_kernel", "residual_parse_kernel")):
+    r = first(prefix)
+    if r:
+        c4[name] = entry(r)
+for name, flag in (("residual_kernel_count", "residual_kernel<false"), ("residual_kernel_write", "residual_kernel<true")):
+    rows = [v[-1] for k, v in kernels.items() if k.startswith(flag) and v]
+    if rows:
+        c4[name] = {"FETCH_SIZE_KiB_raw": sum(r["FETCH_SIZE_KiB_raw"] for r in rows), "WRITE_SIZE_KiB": sum(r["WRITE_SIZE_KiB"] for r in rows),
+                    "hbm_bytes_per_launch": sum(r["hbm_bytes"] for r in rows), "measured": tag,
+                    "note": "upper bound: FETCH_SIZE x 2 over-counts the direct variant's 64-byte requests (DESIGN.md section 5)"}
+t["note_" + tag] = "entries with measured = %s: tools/collect_profiles.sh %s, summarised by tools/pmc_summary.py" % (tag, tag)
+json.dump(t, open(path, "w"), indent=1)
