@@ -35,6 +35,9 @@ shutil.copy(os.path.join(src, "pmc_fetch.csv"), os.path.join(dst, tag + "_pmc_fe
 shutil.copy(os.path.join(src, "pmc_write.csv"), os.path.join(dst, tag + "_pmc_write_size.csv"))
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, tag + "_bench_line.json"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_line_under_rocprof.json"))
+if os.path.exists(os.path.join(src, "main_kernel_stats.csv")):   # the same without the residual leg: the timed kernels only
+    shutil.copy(os.path.join(src, "main_kernel_stats.csv"), os.path.join(dst, tag + "_main_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_main_under_rocprof.json"), os.path.join(dst, tag + "_main_bench_line_under_rocprof.json"))
 
 # launches of one kernel differ by role in bench.py (e.g. residual sizes pass vs records pass): keep every distinct value
 # group — (launch index modulo the pattern is not reconstructed here) — as the median of the timed-region launches and the
