@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x) {
 }
 // (a & m) | (b & ~m)  — v_bfi_b32
 __device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ __forceinline__ uint32_t neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }  // ~0 if bit 31 set
 
 // ---------------------------------------------------------------------------------------------
 // encode
@@ -193,27 +194,48 @@ __device__ __forceinline__ void quad_enc_steps(const QuadEncInfo &f, QuadEnc &e,
 //   bits 4..0 k | bits 8..5 2c | bit 9 LPS path | bit 10 bypass | bit 11 bypass bin 1 | bit 12 align
 struct QuadRecord {  // one bin record of a 16-bin step, with the context state it sees
   uint32_t id, bin, st;
-  bool is_ctx, is_ep, is_trm, is_align;
+  uint32_t ctxm, epm, trmm, alnm;  // 0 / ~0: what kind of record it is (all zero: none — past the end of the substream)
 };
 
+// Written with 0 / ~0 masks throughout (round 2): as booleans the record kinds became lane masks in SGPRs, and the
+// s_and_b64 / s_and_saveexec that combined them each waited ~55 cycles for a vector compare — six to eight times per
+// step in the context wave, which every encoder since v5 waits for.
+constexpr uint32_t kMatchWords = 1024;  // per wave: which lanes of a row hold which record id, 16 bits per row and id, two rows per word
+// `match` (optional, LDS, all zero between calls): the lanes of a row with the same id found through LDS instead of with nine
+// ballots — every lane ORs its bit into the word of its id, reads the word back and clears it: three LDS instructions and
+// one round trip instead of 36 vector instructions that write scalar registers (measured alone, tools/ubench_ctx.hip:
+// the nine-round match-any is 160 of quad_phase_a's 350 ns)
 template <uint32_t kLowestSpecial = CABAC_REC_ALIGN>  // ids from here up to 0x1FF are not "bad" (the estimator has two more)
 __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                   uint32_t &bad) {
+                                                   uint32_t &bad, uint32_t *match = nullptr) {
   QuadRecord q;
-  const uint32_t id = active ? (r & CABAC_REC_ID_MASK) : CABAC_REC_ID_MASK;
+  uint32_t actm = active ? ~0u : 0u;
+  asm volatile("" : "+v"(actm));   // opaque: hipcc otherwise turns the mask arithmetic below back into lane-mask booleans
+  const uint32_t id = sel(actm, r & CABAC_REC_ID_MASK, CABAC_REC_ID_MASK);
   const uint32_t bin = (r >> 15) & 1u;
-  const bool is_ctx = id < (uint32_t)kNumCtx;
-  const bool is_ep = active && id == CABAC_REC_EP;
-  const bool is_trm = active && id == CABAC_REC_TRM;
-  const bool is_align = active && id == CABAC_REC_ALIGN;
-  if (active && !is_ctx && id < kLowestSpecial) bad = 1;
+  const uint32_t ctxm = neg_mask(id - (uint32_t)kNumCtx);                         // id < 379 (an inactive lane's id is 0x1FF)
+  const uint32_t epm = actm & neg_mask((id ^ CABAC_REC_EP) - 1u);
+  const uint32_t trmm = actm & neg_mask((id ^ CABAC_REC_TRM) - 1u);
+  const uint32_t alnm = actm & neg_mask((id ^ CABAC_REC_ALIGN) - 1u);
+  bad |= actm & ~ctxm & neg_mask(id - kLowestSpecial) & 1u;
   const uint32_t j = lane & 15u;
-  const uint32_t same = (uint32_t)(match_any_bits<9>(id, 0xffffull << (16u * row)) >> (16u * row)) & 0xffffu;
+  uint32_t same;
+  if (match != nullptr) {
+    uint32_t *word = match + ((row >> 1) << 9) + id;
+    const uint32_t shift = ((row & 1u) << 4);
+    atomicOr(word, 1u << (shift + j));
+    asm volatile("" ::: "memory");                 // one wave: LDS executes its instructions in order
+    same = (*(volatile uint32_t *)word >> shift) & 0xffffu;
+    asm volatile("" ::: "memory");
+    *word = 0u;
+  } else {
+    same = (uint32_t)(match_any_bits<9>(id, 0xffffull << (16u * row)) >> (16u * row)) & 0xffffu;
+  }
   const uint32_t binmask = (uint32_t)(__ballot(bin != 0) >> (16u * row)) & 0xffffu;  // the bins of this row
   const uint32_t before = same & ((1u << j) - 1u);      // earlier bins of the same context in this step
-  const bool is_last = (same >> j) == 1u;                // no later one
+  const uint32_t lastm = neg_mask(((same >> j) ^ 1u) - 1u);  // no later one
   const uint32_t stored = rctx[min(id, (uint32_t)kNumCtx)];  // unconditional load (slot kNumCtx: the row's pad word)
-  uint32_t st = is_ctx ? stored : 0u;
+  uint32_t st = stored & ctxm;
   // The state this bin sees is the stored one updated by those earlier bins, oldest first.  Their values are
   // known (encoder), so every lane walks its own `before` set — no hand-over between lanes, hence no LDS
   // round trip per repetition of a context.  update(), contexts.cpp:903-913, on both 15-bit estimators at
@@ -228,38 +250,49 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
     const u16x2 b2 = __builtin_bit_cast(u16x2, b | (b << 16));
     return __builtin_bit_cast(uint32_t, (u16x2)(add2 * b2 + (s2 - ((s2 >> rate2) & mask2))));
   };
-  uint32_t todo = is_ctx ? before : 0u;
-  for (int round = 0;; round++) {  // two repetitions unconditionally (mask arithmetic, no branch), more if needed
-    if (round >= 2 && __ballot(todo != 0) == 0) break;
+  uint32_t todo = before & ctxm;
+  // two repetitions unconditionally (mask arithmetic, no branch), more if some lane has a third: asked here, two rounds
+  // before the answer is branched on
+  const uint32_t after2 = todo & (todo - 1u);
+  uint64_t more = __ballot((after2 & (after2 - 1u)) != 0u);
+  asm volatile("" : "+s"(more));
+  auto one_round = [&]() {
     const uint32_t valid = (uint32_t)((int32_t)(0u - todo) >> 31);
     const uint32_t which = (uint32_t)__builtin_ctz(todo | 0x10000u);
     const uint32_t b = (binmask >> which) & 1u;
     st = sel(valid, updated(st, b), st);
     todo &= todo - 1u;
+  };
+  one_round();
+  one_round();
+  if (__builtin_expect(more != 0, 0)) {
+    for (int round = 2; round < 16; round++) {
+      one_round();
+      if (__ballot(todo != 0) == 0) break;
+    }
   }
-  if (is_ctx && is_last) rctx[id] = updated(st, bin);
+  rctx[sel(ctxm & lastm, id, (uint32_t)kNumCtx)] = updated(st, bin);  // others write the pad word
   q.id = id;
   q.bin = bin;
   q.st = st;
-  q.is_ctx = is_ctx;
-  q.is_ep = is_ep;
-  q.is_trm = is_trm;
-  q.is_align = is_align;
+  q.ctxm = ctxm;
+  q.epm = epm;
+  q.trmm = trmm;
+  q.alnm = alnm;
   return q;
 }
 
 __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                 uint32_t &bad) {
-  const QuadRecord q = quad_resolve(r, active, lane, row, rctx, bad);
+                                                 uint32_t &bad, uint32_t *match = nullptr) {
+  const QuadRecord q = quad_resolve(r, active, lane, row, rctx, bad, match);
   const uint32_t bin = q.bin;
   const uint32_t q8 = ctx2_q8(q.st);
   const uint32_t mps = q8 >> 7;
-  uint32_t info = 0;  // inactive lanes: a no-op step (t = 0, no shift)
-  if (q.is_ctx) info = ctx2_k(q8) | (8u << 5) | ((bin ^ mps) << 9);
-  if (q.is_trm) info = (4u << 5) | (bin << 9);  // terminate == LPS width 2 (arith_codec.cpp:460-478)
-  if (q.is_ep) info = (1u << 10) | (bin << 11);
-  if (q.is_align) info = 1u << 12;
-  return info;
+  // inactive lanes: a no-op step (t = 0, no shift); the kinds exclude each other
+  return ((ctx2_k(q8) | (8u << 5) | ((bin ^ mps) << 9)) & q.ctxm) |
+         (((4u << 5) | (bin << 9)) & q.trmm) |          // terminate == LPS width 2 (arith_codec.cpp:460-478)
+         (((1u << 10) | (bin << 11)) & q.epm) |
+         ((1u << 12) & q.alnm);
 }
 
 __device__ __forceinline__ QuadEncInfo quad_unpack(uint32_t info) {
@@ -378,9 +411,8 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {  // lane j gets lane j
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
 }
 
-// Everything below is written with 0 / ~0 masks in VGPRs: boolean expressions become lane masks in SGPRs,
+// Everything below is written with 0 / ~0 masks in VGPRs (neg_mask, sel): boolean expressions become lane masks in SGPRs,
 // and every scalar instruction that consumes a vector result stalls the wave for ~55 cycles.
-__device__ __forceinline__ uint32_t neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }  // ~0 if bit 31 set
 
 struct QuadUnits {
   uint32_t m;            // units of this step in the row (0..8)
@@ -389,10 +421,13 @@ struct QuadUnits {
   uint64_t store_lanes;  // lanes that will store a unit
 };
 
-// Part 1: lanes 0..3 of a row list the units of posts 0..3 in stream order.
+// Part 1: lanes 0..3 of a row list the units of posts 0..3 in stream order.  kHalfRows: a substream has EIGHT lanes (two
+// substreams per 16-lane DPP row, j = lane & 7) — eight is the most units a step can produce, and lanes 4..7 of a group
+// count nothing, so the row shifts never carry a count across the two groups of a row.
+template <bool kHalfRows = false>
 __device__ __forceinline__ QuadUnits quad_list_units(const QuadEnc &e, const uint32_t *plo, const uint32_t *phi,
                                                      const uint32_t *ppend, uint32_t row, uint32_t j, bool live,
-                                                     uint32_t *list) {
+                                                     uint32_t *list, uint32_t lane = 0) {
   const uint32_t c = (j & 3u) * kQuadSubs + row;  // lanes >= 4 read along, and count nothing
   const uint64_t low = ((uint64_t)phi[c] << 32) | plo[c];
   const uint32_t pend = ppend[c];
@@ -408,10 +443,11 @@ __device__ __forceinline__ QuadUnits quad_list_units(const QuadEnc &e, const uin
   list[sel(has1, idx, kUnitDump)] = first;
   list[sel(has2, idx + 1u, kUnitDump)] = second;
   QuadUnits u;
-  u.m = row_bcast<3>(incl);
+  if (kHalfRows) u.m = (lane & 8u) ? row_bcast<11>(incl) : row_bcast<3>(incl);
+  else u.m = row_bcast<3>(incl);
   const uint32_t room = e.cap - e.pos - 2u * u.m;                     // negative: the buffer would overflow
   const uint32_t rowodd = neg_mask(0u - u.m) & (neg_mask(0u - ((uint32_t)e.nbuf ^ 1u)) | neg_mask(room));
-  u.odd_rows = __ballot(rowodd != 0);
+  u.odd_rows = __ballot(live && rowodd != 0);   // (rows without a substream never store: nothing to be careful about)
   u.store_lanes = __ballot(live && j < u.m);
   return u;
 }
@@ -766,10 +802,15 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   __shared__ uint32_t unit_list[U][kRing][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
   __shared__ uint32_t unit_count[U][kRing][kQuadSubs];
   __shared__ uint32_t fin_acc[U][kQuadSubs], fin_rem[U][kQuadSubs];
+  __shared__ uint32_t match_all[U][kMatchWords];   // the context waves' same-id bitmaps (quad_resolve)
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: low wave, 3: emit wave
+  // through LDS where the SIMDs are the limit (four units per CU: C4 v7 0.81 -> 0.73 ms), with ballots where one unit has
+  // the CU to itself and the two LDS round trips would show (C3: 16.0 against 16.6 ms)
+  constexpr bool kLdsMatch = U == 4;
+  for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += 256u * U) (&match_all[0][0])[k] = 0u;
   const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
@@ -794,7 +835,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     auto rec_of = [&](uint32_t step) { return (uint32_t)rec_safe[min(16u * step + j, last_rec)]; };
-    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a(r, 16u * step + j < n, lane, row, rctx, bad); };
+    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a(r, 16u * step + j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr); };
     // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
     // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
     uint32_t ahead[4];  // the records of the next four steps
@@ -1011,7 +1052,7 @@ __device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&dst)[16
 }
 
 template <int U>
-__global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+__global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                                       const uint16_t *__restrict__ records,
                                                                       uint8_t *__restrict__ bytes,
                                                                       cabac_substream_result *__restrict__ results) {
@@ -1022,22 +1063,43 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
   __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];  // low -> output (v5's posts)
   __shared__ uint32_t fin_lo[S], fin_hi[S], fin_pend[S];
   __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
-  __shared__ uint32_t special[4][U];
+  __shared__ uint32_t match_all[U][kMatchWords];   // the context waves' same-id bitmaps (quad_resolve)
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves; then, for U = 4, two output
-  // waves, the chain wave, the low wave and the other two output waves — the chain and the low wave, the longest, each
-  // share their SIMD with one context wave only; for U = 1 context, chain, low, output on a SIMD each.
-  constexpr uint32_t kChainWave = U == 4 ? 6 : U, kLowWave = kChainWave + 1u;
+  constexpr bool kLdsMatch = U == 4;   // see encode_kernel_v6
+  for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += blockDim.x) (&match_all[0][0])[k] = 0u;
+  // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves (lane = (row, bin) of one unit's
+  // four substreams), the chain wave, the low wave (lane = substream), then (U + 1) / 2 output waves with EIGHT lanes per
+  // substream (eight substreams = two units per wave).  For U = 4: eight waves, two per SIMD, ~385 instructions per SIMD
+  // and step on each.
+  constexpr uint32_t kChainWave = U, kLowWave = U + 1u;
   const bool is_ctx = wave < (uint32_t)U, is_chain = wave == kChainWave, is_low = wave == kLowWave;
-  const bool is_out = !is_ctx && !is_chain && !is_low;
-  const bool quad = is_ctx || is_out;                       // lane = (row, bin / unit index) of one unit's four substreams
-  const uint32_t unit = is_ctx ? wave : (wave < kChainWave ? wave - (uint32_t)U : wave - (uint32_t)U - 2u);
-  const uint32_t row = lane >> 4, j = lane & 15u;
-  const uint32_t local = quad ? unit * kQuadSubs + row : min(lane, S - 1u);  // chain / low: lane = substream
+  const bool is_out = wave > kLowWave;
+  // the substream of this thread
+  uint32_t row, j, unit, local;
+  bool in_range = true;
+  if (is_ctx) {
+    row = lane >> 4;
+    j = lane & 15u;
+    unit = wave;
+    local = unit * kQuadSubs + row;
+  } else if (is_out) {
+    const uint32_t g = (wave - kLowWave - 1u) * 8u + (lane >> 3);   // substream of the workgroup
+    in_range = g < S;
+    local = min(g, S - 1u);
+    unit = local >> 2;
+    row = local & 3u;
+    j = lane & 7u;
+  } else {
+    row = lane >> 4;
+    j = lane & 15u;
+    unit = 0;
+    in_range = lane < S;
+    local = min(lane, S - 1u);
+  }
   const uint32_t sub = blockIdx.x * S + local;
-  const bool live = sub < n_sub && (quad || lane < S);
+  const bool live = sub < n_sub && in_range;
   const cabac_substream_desc d = desc[sub < n_sub ? sub : 0];
   const uint32_t n = sub < n_sub ? d.n_records : 0u;
 
@@ -1067,13 +1129,11 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
       fld[slot][kV7Lp9][at] = (lpsm | pem) & 0x1ffu;   // the bin adds its MPS sub-range to low: LPS, or a bypass bin 1
       fld[slot][kV7Ep][at] = (info >> 10) & 1u;
       fld[slot][kV7Alm][at] = bit_mask<12>(info);
-      const uint64_t any = __ballot((info >> 12) != 0);
-      if (lane == 0) special[slot][unit] = any != 0 ? 1u : 0u;
     };
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
     uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
-    post(0, quad_phase_a(cur_rec, j < n, lane, row, rctx, bad));  // step 0
+    post(0, quad_phase_a(cur_rec, j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr));  // step 0
     __syncthreads();
     for (uint32_t k = 0; k < n_steps; k++) {
       const uint32_t base = 16u * k;
@@ -1083,7 +1143,7 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
       ahead2 = ahead3;
       ahead3 = rec_safe[min(base + 80u + j, last_rec)];
       V5_TICK(t0);
-      post((k + 1u) & 3u, quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad));
+      post((k + 1u) & 3u, quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr));
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
@@ -1114,18 +1174,12 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
         lds_read4(&fld[slot][kV7C2][local * kV7Pad], q, c2);
         lds_read4(&fld[slot][kV7Lpsm][local * kV7Pad], q, lm);
       }
-      uint32_t any = 0;
+      // always with the align() handling (one select per bin): asking whether the step has such a record would cost the
+      // context waves — which everything waits for — a ballot and a store per step
+      uint32_t al[16];
+      lds_read16(&fld[slot][kV7Alm][local * kV7Pad], al);
 #pragma unroll
-      for (int q = 0; q < U; q++) any |= special[slot][q];
-      if (__builtin_amdgcn_readfirstlane((int)any) == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = lane_rng_step<false>(kk[i], c2[i], lm[i], 0u, range);
-      } else {
-        uint32_t al[16];
-        lds_read16(&fld[slot][kV7Alm][local * kV7Pad], al);
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = lane_rng_step<true>(kk[i], c2[i], lm[i], al[i], range);
-      }
+      for (int i = 0; i < 16; i++) w[i] = lane_rng_step<true>(kk[i], c2[i], lm[i], al[i], range);
       uint4 *dst = reinterpret_cast<uint4 *>(&wpost[k & 1u][lane * kV7Pad]);
 #pragma unroll
       for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
@@ -1195,7 +1249,7 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
     __syncthreads();
     __syncthreads();
   } else {
-    // ---- output waves: v5's (quad_list_units / quad_emit_units), two steps behind the chain ----------------------
+    // ---- output waves: v5's (quad_list_units / quad_emit_units) with eight lanes per substream, two steps behind the chain ----
     QuadEnc e;
     e.low = 0;
     e.range = 0;
@@ -1206,14 +1260,14 @@ __global__ __launch_bounds__(64 * (2 * U + 2)) void encode_kernel_v7(uint32_t n_
     e.dst = bytes + d.byte_offset;
     e.cap = live ? d.byte_capacity : 0u;
     const bool writer = live && j == 0;
-    uint32_t *list = unit_list[unit][row];
+    uint32_t *list = unit_list[unit][row];   // (lanes past the last substream of the workgroup share the last one's; they never store)
     QuadUnits units;
     units.m = 0;
     units.odd_rows = 0;
     units.store_lanes = 0;
     bool listed = false;
     auto list_step = [&](uint32_t k) {
-      units = quad_list_units(e, post_lo[unit][k & 1u], post_hi[unit][k & 1u], post_pend[unit][k & 1u], row, j, live, list);
+      units = quad_list_units<true>(e, post_lo[unit][k & 1u], post_hi[unit][k & 1u], post_pend[unit][k & 1u], row, j, live, list, lane);
     };
     __syncthreads();
     for (uint32_t k = 0; k < n_steps; k++) {
@@ -1724,10 +1778,10 @@ __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const 
     const bool active = base + j < n;
     const bool zero = active && q.id == CABAC_REC_EST_RESETBITS, whole = active && q.id == CABAC_REC_EST_RESTART;
     uint32_t cost = 0;
-    if (q.is_ctx) cost = frac[2u * ctx2_q8(q.st) + q.bin];
-    if (q.is_ep) cost = 1u << 15;                     // estFracBitsEP, contexts.cpp:880-882
-    if (q.is_trm) cost = q.bin ? 0x3bfbbu : 0x0010cu;  // estFracBitsTrm, contexts.cpp:931-933
-    const uint32_t special = q.is_align ? 1u : zero ? 2u : whole ? 3u : 0u;  // records that need the total in order
+    if (q.ctxm) cost = frac[2u * ctx2_q8(q.st) + q.bin];
+    if (q.epm) cost = 1u << 15;                       // estFracBitsEP, contexts.cpp:880-882
+    if (q.trmm) cost = q.bin ? 0x3bfbbu : 0x0010cu;    // estFracBitsTrm, contexts.cpp:931-933
+    const uint32_t special = q.alnm ? 1u : zero ? 2u : whole ? 3u : 0u;  // records that need the total in order
     if (__builtin_expect(__ballot(special != 0) != 0, 0)) {
       uint64_t total = row_sum64(acc);  // everything before this step
       for (int k = 0; k < 16; k++) {
@@ -1808,7 +1862,7 @@ hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   // sixteen substreams per workgroup once there are enough of them to give every CU one; four below that
-  if (max(n_sub, in_flight) >= 1024u) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3((n_sub + 15) / 16), dim3(640), 0, st, n_sub, desc, records, bytes, results);
+  if (max(n_sub, in_flight) >= 1024u) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3((n_sub + 15) / 16), dim3(512), 0, st, n_sub, desc, records, bytes, results);
   else hipLaunchKernelGGL(encode_kernel_v7<1>, dim3((n_sub + 3) / 4), dim3(256), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }

@@ -80,7 +80,7 @@ def first(prefix):
     return None
 
 
-for name, prefix in (("encode_kernel_v6", "encode_kernel_v6"), ("decode_kernel_v4", "decode_kernel_v4"), ("estimate_kernel", "estimate_kernel"),
+for name, prefix in (("encode_kernel_v6", "encode_kernel_v6"), ("encode_kernel_v7", "encode_kernel_v7"), ("decode_kernel_v4", "decode_kernel_v4"), ("estimate_kernel", "estimate_kernel"),
                      ("residual_parse_kernel", "residual_parse_kernel")):
     r = first(prefix)
     if r:

@@ -72,7 +72,7 @@ int main() {
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v5_prof), z, sizeof(z));
       hipEvent_t c, d; (void)hipEventCreate(&c); (void)hipEventCreate(&d);
       (void)hipEventRecord(c);
-      if (uu == 0) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3(n_sub / 16), dim3(640), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
+      if (uu == 0) hipLaunchKernelGGL(encode_kernel_v7<4>, dim3(n_sub / 16), dim3(512), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
       else hipLaunchKernelGGL(encode_kernel_v7<1>, dim3(n_sub / 4), dim3(256), 0, 0, n_sub, d_desc, d_rec, d_bytes, d_res);
       (void)hipEventRecord(d); (void)hipDeviceSynchronize();
       float vms; (void)hipEventElapsedTime(&vms, c, d);
