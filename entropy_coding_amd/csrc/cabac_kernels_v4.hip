@@ -225,7 +225,7 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
     const uint32_t shift = ((row & 1u) << 4);
     atomicOr(word, 1u << (shift + j));
     asm volatile("" ::: "memory");                 // one wave: LDS executes its instructions in order
-    same = (*(volatile uint32_t *)word >> shift) & 0xffffu;
+    same = (*word >> shift) & 0xffffu;             // (not through a volatile pointer: that becomes a system-scope flat load)
     asm volatile("" ::: "memory");
     *word = 0u;
   } else {
@@ -807,9 +807,8 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: low wave, 3: emit wave
-  // through LDS where the SIMDs are the limit (four units per CU: C4 v7 0.81 -> 0.73 ms), with ballots where one unit has
-  // the CU to itself and the two LDS round trips would show (C3: 16.0 against 16.6 ms)
-  constexpr bool kLdsMatch = U == 4;
+  // the same-id lanes of the context wave through LDS (quad_resolve): C4 0.85 -> 0.81 ms, C3 16.3 -> 15.8 ms
+  constexpr bool kLdsMatch = true;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += 256u * U) (&match_all[0][0])[k] = 0u;
   const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
   const bool live = sub < n_sub;
@@ -1067,7 +1066,9 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  constexpr bool kLdsMatch = U == 4;   // see encode_kernel_v6
+  // same-id lanes through LDS where four context waves share a CU with the rest (C4 0.81 -> 0.69 ms); with one context wave
+  // the nine ballots are faster here (C3 16.1 against 16.4 ms)
+  constexpr bool kLdsMatch = U == 4;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += blockDim.x) (&match_all[0][0])[k] = 0u;
   // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves (lane = (row, bin) of one unit's
   // four substreams), the chain wave, the low wave (lane = substream), then (U + 1) / 2 output waves with EIGHT lanes per
