@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // before (they arrive during its chain), the rest at its END (the context store has just been written back).
   uint32_t rec1 = rec_safe[min(j, last_rec)], rec2 = rec_safe[min(16u + j, last_rec)], rec3 = rec_safe[min(32u + j, last_rec)];
   uint32_t prev_bin = 0, prev_idx = ~0u;  // the bins of the previous step, not yet stored
+  uint64_t prev_lanes = 0;                 // ... and the lanes that have one
   uint32_t nxt_id, nxt_actm;
   uint4 nxt_a, nxt_b;
   auto request = [&](uint32_t base) {  // stage 1 for the step at `base`: its ids and their table rows
@@ -1661,7 +1662,11 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     // one in-order counter, so a store issued before a wait would add its whole latency to it (the same goes for the
     // input block requested a step ago: into the ring with it before anything new is issued)
     if ((base & 48u) == 16u) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
-    if (prev_idx < n) out[prev_idx] = (uint8_t)prev_bin;
+    {  // under the lane mask asked for at the end of the step before: an `if` here is a compare the scalar unit waits for
+      uint64_t saved;
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_byte %2, %3, off\n\ts_mov_b64 exec, %0"
+                   : "=&s"(saved) : "s"(prev_lanes), "v"(out + min(prev_idx, last_rec)), "v"(prev_bin) : "memory");
+    }
     if ((base & 48u) == 0u) quad_dec_stage_load(w, j);    // steps 0, 4, 8, ...: request a block of input
     const uint32_t id = cur_id, ctxm = cur_ctxm;
     // asked long ago, needed now (the choice of the step variant): the branch finds the answer waiting
@@ -1679,6 +1684,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
+    prev_lanes = __ballot(prev_idx < n);
     prepare();                                      // the next step's context states and record fields
     V5_TICK(t4);
     if (wave == 0) {
