@@ -20,7 +20,7 @@ SHORT="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 $SHORT > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python3 $SHORT > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || exit 4
 # keep what is small enough to travel back: the stats summary and the per-dispatch counter rows of our kernels
-find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 for k in fetch write; do
   f=$(find "$OUT/pmc_$k" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "$OUT/pmc_$k.csv" <<'PY'
