@@ -1218,11 +1218,11 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
         pend += sh;
         if ((i & 3) == 3) {
           const uint32_t c = (uint32_t)(i >> 2) * kQuadSubs + pr;
-          if (lane < S) {
-            post_lo[pu][k & 1u][c] = (uint32_t)low;
-            post_hi[pu][k & 1u][c] = (uint32_t)(low >> 32);
-            post_pend[pu][k & 1u][c] = pend;
-          }
+          // (no `if (lane < S)`: the lanes past the last substream mirror it — same fields, same values — and an `if`
+          // is a compare the scalar unit waits for, four times per step)
+          post_lo[pu][k & 1u][c] = (uint32_t)low;
+          post_hi[pu][k & 1u][c] = (uint32_t)(low >> 32);
+          post_pend[pu][k & 1u][c] = pend;
           // whole units, and the carry above them, now belong to the post; without a whole unit nothing is cut
           const uint32_t keep = pend & 15u;
           const uint32_t width = pend >= 16u ? 9u + keep : 63u;
@@ -1242,11 +1242,9 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       V5_ADD(5, t1, t2);
     }
     if (n_steps != 0) low_step(n_steps - 1u);
-    if (lane < S) {
-      fin_lo[local] = (uint32_t)low;
-      fin_hi[local] = (uint32_t)(low >> 32);
-      fin_pend[local] = pend;
-    }
+    fin_lo[local] = (uint32_t)low;
+    fin_hi[local] = (uint32_t)(low >> 32);
+    fin_pend[local] = pend;
     __syncthreads();
     __syncthreads();
   } else {
