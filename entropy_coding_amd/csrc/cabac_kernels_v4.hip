@@ -1058,7 +1058,9 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
   constexpr uint32_t S = U * kQuadSubs;
   __shared__ uint32_t ctx_all[S * kQuadCtxStride];
   __shared__ __attribute__((aligned(16))) uint32_t fld[4][kV7Fields][S * kV7Pad];  // context waves -> chain / low wave
-  __shared__ __attribute__((aligned(16))) uint32_t wpost[2][64 * kV7Pad];           // chain -> low: rm | shift << 9 per bin
+  // chain -> low: rm | shift << 9 per bin; one row per substream and one that all lanes past the last substream share (they
+  // mirror it: same values) — LDS is what decides whether two workgroups fit on a CU (76 KB each)
+  __shared__ __attribute__((aligned(16))) uint32_t wpost[2][(S + 1) * kV7Pad];
   __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];  // low -> output (v5's posts)
   __shared__ uint32_t fin_lo[S], fin_hi[S], fin_pend[S];
   __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
@@ -1181,7 +1183,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       lds_read16(&fld[slot][kV7Alm][local * kV7Pad], al);
 #pragma unroll
       for (int i = 0; i < 16; i++) w[i] = lane_rng_step<true>(kk[i], c2[i], lm[i], al[i], range);
-      uint4 *dst = reinterpret_cast<uint4 *>(&wpost[k & 1u][lane * kV7Pad]);
+      uint4 *dst = reinterpret_cast<uint4 *>(&wpost[k & 1u][min(lane, S) * kV7Pad]);
 #pragma unroll
       for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
       V5_TICK(t1);
@@ -1203,7 +1205,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       uint32_t w[16], lp9[16], ep[16];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        lds_read4(&wpost[k & 1u][lane * kV7Pad], q, w);
+        lds_read4(&wpost[k & 1u][min(lane, S) * kV7Pad], q, w);
         lds_read4(&fld[slot][kV7Lp9][local * kV7Pad], q, lp9);
         lds_read4(&fld[slot][kV7Ep][local * kV7Pad], q, ep);
       }
