@@ -1330,7 +1330,7 @@ struct QuadDec {   // row-uniform values
 struct QuadDecInfo {
   uint32_t c2;    // 2 * constant term of the LPS width: 8 context bin, 4 terminate bin, 0 bypass / none
   uint32_t ep;    // 1 for a bypass bin
-  uint32_t srmul; // 2^(22 - ep): the bypass doubling of value (arith_codec.cpp:100-105) is done by comparing against
+  uint32_t srmul; // -2^(22 - ep) (as a signed 24-bit factor): the bypass doubling of value (arith_codec.cpp:100-105) is done by comparing against
                   // scaledRange / 2 and shifting afterwards, together with the renormalisation
   uint32_t ctxm;  // ~0 for a context-coded bin
   uint32_t ntrm;  // 0 for a terminate bin, ~0 otherwise            (kSpecial steps only)
@@ -1426,8 +1426,9 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   // scaledRange at the window's scale, 2^22 (2^21 for a bypass bin) * rm.  As a multiplication on purpose: hipcc
   // folds the broadcast into the consumer, and v_lshlrev_b32 with DPP on its shift-amount operand returned
   // wrong results on gfx950 (bisected with the parity tests); v_mul_u32_u24 with DPP is fine.
-  const uint32_t sr = __umul24(rm, u.srmul[I]);
-  const uint32_t e = w.hi - sr;                                  // value - scaledRange; both are below 2^31
+  // value - scaledRange in ONE instruction: the record's field is MINUS the scale, a signed 24-bit factor (v_mad_i32_i24)
+  uint32_t e;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e) : "v"(rm), "v"(u.srmul[I]), "v"(w.hi));
   // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0.  Through asm so that hipcc sees an opaque mask: written
   // as (int)e >> 31 it turns every use back into v_cmp + v_cndmask pairs, two instructions where a v_bfi /
   // v_bitop3 on the mask is one.
@@ -1538,7 +1539,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
       r0_v = r0 | (r1 << 16);  // packed shift amounts for the 2 x 16-bit update
     }
     rec_tab[id][0] = (8u & ctxm) | (4u & trm_m);  // 2 * constant term of the LPS width
-    rec_tab[id][1] = 0x400000u >> ep;             // 2^(22 - ep)
+    rec_tab[id][1] = 0u - (0x400000u >> ep);      // -2^(22 - ep), see quad_dec_step
     rec_tab[id][2] = ctxm;
     rec_tab[id][3] = ep;
     rec_tab[id][4] = r0_v;

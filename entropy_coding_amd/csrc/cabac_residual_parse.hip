@@ -175,7 +175,9 @@ __device__ __forceinline__ uint32_t pd_bin(D &d, uint4 *ctx, uint32_t slot) {
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
   const uint32_t t = (__umul24(d.range >> 5, k) + 8u) >> 1;     // ((range >> 5) * k >> 1) + 4
   const uint32_t rm = d.range - t;
-  const uint32_t ev = d.hi - (rm << 22);                        // value - scaledRange
+  uint32_t ev;                                                  // value - scaledRange
+  if (D::kScalar) ev = d.hi - (rm << 22);
+  else asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ev) : "v"(rm), "v"(0xffc00000u), "v"(d.hi));  // rm * -2^22 + value: one instruction
   const bool mps = (int32_t)ev < 0;
   const uint32_t bin = (mps ? sx : ~sx) & 1u;
   // renormalisation, one rule for both paths: the chosen sub-range shifted up to [256, 511] — LPS by getRenormBitsLPS =
