@@ -178,12 +178,20 @@ __device__ __forceinline__ uint32_t pd_bin(D &d, uint4 *ctx, uint32_t slot) {
   uint32_t ev;                                                  // value - scaledRange
   if (D::kScalar) ev = d.hi - (rm << 22);
   else asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ev) : "v"(rm), "v"(0xffc00000u), "v"(d.hi));  // rm * -2^22 + value: one instruction
-  const bool mps = (int32_t)ev < 0;
-  const uint32_t bin = (mps ? sx : ~sx) & 1u;
   // renormalisation, one rule for both paths: the chosen sub-range shifted up to [256, 511] — LPS by getRenormBitsLPS =
   // clz(t) - 23; MPS by one bit iff rm < 256, which is clz(rm) - 23 because rm >= 128 (an LPS width is at most 15.5 / 32
   // of the range plus 4)
-  const uint32_t x = mps ? rm : t;
+  uint32_t bin, x;
+  if (D::kScalar) {
+    const bool mps = (int32_t)ev < 0;
+    bin = (mps ? sx : ~sx) & 1u;
+    x = mps ? rm : t;
+  } else {
+    uint32_t ngem;  // ~0: value < scaledRange (MPS).  Through asm: as (int)ev >> 31 hipcc turns every use back into v_cmp + v_cndmask pairs
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(ev));
+    bin = ~(ngem ^ sx) & 1u;
+    x = (rm & ngem) | (t & ~ngem);
+  }
   const uint32_t nsh = (uint32_t)__builtin_clz(x) - 23u;
   d.hi = min(d.hi, ev);   // ev wraps above 2^31 exactly when value < scaledRange
   d.range = x << nsh;
