@@ -1423,9 +1423,9 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
   const uint32_t t = (__umul24(w.range >> 5, k) + u.c2[I]) >> 1;
   const uint32_t rm = w.range - t;
-  // scaledRange at the window's scale, 2^22 (2^21 for a bypass bin) * rm.  As a multiplication on purpose: hipcc
-  // folds the broadcast into the consumer, and v_lshlrev_b32 with DPP on its shift-amount operand returned
-  // wrong results on gfx950 (bisected with the parity tests); v_mul_u32_u24 with DPP is fine.
+  // scaledRange at the window's scale is 2^22 (2^21 for a bypass bin) * rm.  (Round 1 had the scale as a DPP operand of a
+  // multiplication, because v_lshlrev_b32 with DPP on its shift-amount operand returned wrong results on gfx950 — bisected
+  // with the parity tests.)
   // value - scaledRange in ONE instruction: the record's field is MINUS the scale, a signed 24-bit factor (v_mad_i32_i24)
   uint32_t e;
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e) : "v"(rm), "v"(u.srmul[I]), "v"(w.hi));
