@@ -660,7 +660,7 @@ def main():
             "hash_match": bool(hash_match and ok),
             "roofline": {
                 "bound": "hbm",        # the roof the tier prices against; what limits these kernels is in `limiter`
-                "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD issues one instruction per ~2 ns: ~655 per 16-bin decode step); HBM traffic equals the algorithmic bytes",
+                "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD issues one instruction per ~2 ns: ~640 per 16-bin decode step); HBM traffic equals the algorithmic bytes",
                 "kernel": k_dom,
                 "achieved": round(ach, 3),
                 "peak": HBM_PEAK_GBPS,
