@@ -251,11 +251,12 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
     return __builtin_bit_cast(uint32_t, (u16x2)(add2 * b2 + (s2 - ((s2 >> rate2) & mask2))));
   };
   uint32_t todo = before & ctxm;
-  // two repetitions unconditionally (mask arithmetic, no branch), more if some lane has a third: asked here, two rounds
-  // before the answer is branched on
-  const uint32_t after2 = todo & (todo - 1u);
-  uint64_t more = __ballot((after2 & (after2 - 1u)) != 0u);
-  asm volatile("" : "+s"(more));
+  // How many repetitions the wave needs is asked right here (three ballots on todo with its lowest one / two bits
+  // removed), long before the answers are branched on: a round is ten vector instructions for all lanes, and most
+  // steps need none or one.
+  const uint32_t after1 = todo & (todo - 1u), after2 = after1 & (after1 - 1u);
+  uint64_t any1 = __ballot(todo != 0u), any2 = __ballot(after1 != 0u), more = __ballot(after2 != 0u);
+  asm volatile("" : "+s"(any1), "+s"(any2), "+s"(more));
   auto one_round = [&]() {
     const uint32_t valid = (uint32_t)((int32_t)(0u - todo) >> 31);
     const uint32_t which = (uint32_t)__builtin_ctz(todo | 0x10000u);
@@ -263,12 +264,16 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
     st = sel(valid, updated(st, b), st);
     todo &= todo - 1u;
   };
-  one_round();
-  one_round();
-  if (__builtin_expect(more != 0, 0)) {
-    for (int round = 2; round < 16; round++) {
+  if (any1 != 0) {
+    one_round();
+    if (any2 != 0) {
       one_round();
-      if (__ballot(todo != 0) == 0) break;
+      if (__builtin_expect(more != 0, 0)) {
+        for (int round = 2; round < 16; round++) {
+          one_round();
+          if (__ballot(todo != 0) == 0) break;
+        }
+      }
     }
   }
   rctx[sel(ctxm & lastm, id, (uint32_t)kNumCtx)] = updated(st, bin);  // others write the pad word
