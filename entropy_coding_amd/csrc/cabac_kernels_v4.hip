@@ -205,7 +205,7 @@ constexpr uint32_t kMatchWords = 1024;  // per wave: which lanes of a row hold w
 // ballots — every lane ORs its bit into the word of its id, reads the word back and clears it: three LDS instructions and
 // one round trip instead of 36 vector instructions that write scalar registers (measured alone, tools/ubench_ctx.hip:
 // the nine-round match-any is 160 of quad_phase_a's 350 ns)
-template <uint32_t kLowestSpecial = CABAC_REC_ALIGN>  // ids from here up to 0x1FF are not "bad" (the estimator has two more)
+template <uint32_t kLowestSpecial = CABAC_REC_ALIGN, bool kLds = false>  // ids from kLowestSpecial up to 0x1FF are not "bad" (the estimator has two more)
 __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
                                                    uint32_t &bad, uint32_t *match = nullptr) {
   QuadRecord q;
@@ -220,7 +220,7 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
   bad |= actm & ~ctxm & neg_mask(id - kLowestSpecial) & 1u;
   const uint32_t j = lane & 15u;
   uint32_t same;
-  if (match != nullptr) {
+  if (kLds) {   // (a template parameter, not `match != nullptr`: an LDS address may be 0, so that test survives to run time)
     uint32_t *word = match + ((row >> 1) << 9) + id;
     const uint32_t shift = ((row & 1u) << 4);
     atomicOr(word, 1u << (shift + j));
@@ -287,9 +287,10 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
   return q;
 }
 
+template <bool kLds = false>
 __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
                                                  uint32_t &bad, uint32_t *match = nullptr) {
-  const QuadRecord q = quad_resolve(r, active, lane, row, rctx, bad, match);
+  const QuadRecord q = quad_resolve<CABAC_REC_ALIGN, kLds>(r, active, lane, row, rctx, bad, match);
   const uint32_t bin = q.bin;
   const uint32_t q8 = ctx2_q8(q.st);
   const uint32_t mps = q8 >> 7;
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     auto rec_of = [&](uint32_t step) { return (uint32_t)rec_safe[min(16u * step + j, last_rec)]; };
-    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a(r, 16u * step + j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr); };
+    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a<kLdsMatch>(r, 16u * step + j < n, lane, row, rctx, bad, match_all[unit]); };
     // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
     // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
     uint32_t ahead[4];  // the records of the next four steps
@@ -1073,9 +1074,8 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  // same-id lanes through LDS where four context waves share a CU with the rest (C4 0.81 -> 0.69 ms); with one context wave
-  // the nine ballots are faster here (C3 16.1 against 16.4 ms)
-  constexpr bool kLdsMatch = U == 4;
+  // same-id lanes of the context waves through LDS (C4 0.81 -> 0.65 ms)
+  constexpr bool kLdsMatch = true;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += blockDim.x) (&match_all[0][0])[k] = 0u;
   // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves (lane = (row, bin) of one unit's
   // four substreams), the chain wave, the low wave (lane = substream), then (U + 1) / 2 output waves with EIGHT lanes per
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
     uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
-    post(0, quad_phase_a(cur_rec, j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr));  // step 0
+    post(0, quad_phase_a<kLdsMatch>(cur_rec, j < n, lane, row, rctx, bad, match_all[unit]));  // step 0
     __syncthreads();
     for (uint32_t k = 0; k < n_steps; k++) {
       const uint32_t base = 16u * k;
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       ahead2 = ahead3;
       ahead3 = rec_safe[min(base + 80u + j, last_rec)];
       V5_TICK(t0);
-      post((k + 1u) & 3u, quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad, kLdsMatch ? match_all[unit] : nullptr));
+      post((k + 1u) & 3u, quad_phase_a<kLdsMatch>(r, base + 16u + j < n, lane, row, rctx, bad, match_all[unit]));
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(64 * W) void estimate_kernel(uint32_t n_sub, const 
   for (uint32_t base = 0; base < max_n; base += 16) {
     const uint32_t r = next_rec;
     next_rec = rec_safe[min(base + 16u + j, last_rec)];
-    const QuadRecord q = quad_resolve<CABAC_REC_EST_RESTART>(r, base + j < n, lane, row, rctx, bad, match_all[wave]);
+    const QuadRecord q = quad_resolve<CABAC_REC_EST_RESTART, true>(r, base + j < n, lane, row, rctx, bad, match_all[wave]);
     const bool active = base + j < n;
     const bool zero = active && q.id == CABAC_REC_EST_RESETBITS, whole = active && q.id == CABAC_REC_EST_RESTART;
     uint32_t cost = 0;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void k_phase_lds(unsigned *out, int iters, unsi
   unsigned acc = 0, bad = 0;
   for (int i = 0; i < iters; i++) {
     const unsigned r = ((i * 37u + lane * 11u + seed) % 379u) | (((i + lane) & 1u) << 15);
-    acc += quad_phase_a(r, true, lane, row, ctx + row * kQuadCtxStride, bad, match);
+    acc += quad_phase_a<true>(r, true, lane, row, ctx + row * kQuadCtxStride, bad, match);
   }
   out[blockIdx.x * 64 + threadIdx.x] = acc + bad;
 }
