@@ -1077,23 +1077,29 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
   // same-id lanes of the context waves through LDS (C4 0.81 -> 0.65 ms)
   constexpr bool kLdsMatch = true;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += blockDim.x) (&match_all[0][0])[k] = 0u;
-  // Roles by wave number (waves are dealt to the CU's four SIMDs in turn): U context waves (lane = (row, bin) of one unit's
-  // four substreams), the chain wave, the low wave (lane = substream), then (U + 1) / 2 output waves with EIGHT lanes per
-  // substream (eight substreams = two units per wave).  For U = 4: eight waves, two per SIMD, ~385 instructions per SIMD
-  // and step on each.
-  constexpr uint32_t kChainWave = U, kLowWave = U + 1u;
-  const bool is_ctx = wave < (uint32_t)U, is_chain = wave == kChainWave, is_low = wave == kLowWave;
-  const bool is_out = wave > kLowWave;
+  // Roles by wave number.  Waves are dealt to the CU's four SIMDs in turn and a SIMD's vector pipe is what bounds this
+  // kernel (SQ counters: 318 vector instructions per SIMD and step x 2 ns = the step), so the roles are ordered to load
+  // the four SIMDs evenly.  For U = 4, eight waves: context 0, context 1, chain, low | context 2, context 3, output 0,
+  // output 1 — two context waves on SIMD 0 and on SIMD 1, chain + output on SIMD 2, low + output on SIMD 3 (~300 each;
+  // with the four context waves first, SIMD 0 had context + chain = 340).  For U = 1: context, chain, low, output.
+  // Context waves: lane = (row, bin) of one unit's four substreams; chain and low wave: lane = substream; output waves:
+  // EIGHT lanes per substream (eight substreams = two units per wave).
+  const uint32_t role_slot = U == 4 ? wave : (wave == 0 ? 0u : wave + 1u);   // U = 1: 0 context, 2 chain, 3 low, 4+ output
+  const bool is_ctx = role_slot < 2u || (U == 4 && (role_slot == 4u || role_slot == 5u));
+  const bool is_chain = role_slot == 2u, is_low = role_slot == 3u;
+  const bool is_out = !is_ctx && !is_chain && !is_low;
+  const uint32_t ctx_unit = role_slot < 2u ? role_slot : role_slot - 2u;          // context waves 0, 1 | 4, 5 -> units 0 .. 3
+  const uint32_t out_index = U == 4 ? role_slot - 6u : 0u;
   // the substream of this thread
   uint32_t row, j, unit, local;
   bool in_range = true;
   if (is_ctx) {
     row = lane >> 4;
     j = lane & 15u;
-    unit = wave;
+    unit = ctx_unit;
     local = unit * kQuadSubs + row;
   } else if (is_out) {
-    const uint32_t g = (wave - kLowWave - 1u) * 8u + (lane >> 3);   // substream of the workgroup
+    const uint32_t g = out_index * 8u + (lane >> 3);   // substream of the workgroup
     in_range = g < S;
     local = min(g, S - 1u);
     unit = local >> 2;
