@@ -205,9 +205,12 @@ constexpr uint32_t kMatchWords = 1024;  // per wave: which lanes of a row hold w
 // ballots — every lane ORs its bit into the word of its id, reads the word back and clears it: three LDS instructions and
 // one round trip instead of 36 vector instructions that write scalar registers (measured alone, tools/ubench_ctx.hip:
 // the nine-round match-any is 160 of quad_phase_a's 350 ns)
-template <uint32_t kLowestSpecial = CABAC_REC_ALIGN, bool kLds = false>  // ids from kLowestSpecial up to 0x1FF are not "bad" (the estimator has two more)
+// `rates` (kRateTab, LDS, 512 entries): the packed shift amounts and addends of the two estimators of every context, looked
+// up instead of derived from the state word's rate bits with ten vector instructions (they depend on the context only:
+// the fourth row of the init table; the estimator, which may start from given rates, derives them)
+template <uint32_t kLowestSpecial = CABAC_REC_ALIGN, bool kLds = false, bool kRateTab = false>  // ids from kLowestSpecial up to 0x1FF are not "bad" (the estimator has two more)
 __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                   uint32_t &bad, uint32_t *match = nullptr) {
+                                                   uint32_t &bad, uint32_t *match = nullptr, const uint2 *rates = nullptr) {
   QuadRecord q;
   uint32_t actm = active ? ~0u : 0u;
   asm volatile("" : "+v"(actm));   // opaque: hipcc otherwise turns the mask arithmetic below back into lane-mask booleans
@@ -241,9 +244,16 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
   // round trip per repetition of a context.  update(), contexts.cpp:903-913, on both 15-bit estimators at
   // once with packed 16-bit math as in the decoder (the rates of a context never change).
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  const uint32_t r0 = (st & 3u) + 2u, r1 = ((st >> 2) & 7u) + 5u;
-  const u16x2 rate2 = __builtin_bit_cast(u16x2, r0 | (r1 << 16));
-  const u16x2 add2 = __builtin_bit_cast(u16x2, ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16));
+  u16x2 rate2, add2;
+  if (kRateTab) {
+    const uint2 ra = rates[id];
+    rate2 = __builtin_bit_cast(u16x2, ra.x);
+    add2 = __builtin_bit_cast(u16x2, ra.y);
+  } else {
+    const uint32_t r0 = (st & 3u) + 2u, r1 = ((st >> 2) & 7u) + 5u;
+    rate2 = __builtin_bit_cast(u16x2, r0 | (r1 << 16));
+    add2 = __builtin_bit_cast(u16x2, ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16));
+  }
   const u16x2 mask2 = __builtin_bit_cast(u16x2, (kMask1 << 16) | kMask0);
   auto updated = [&](uint32_t s, uint32_t b) {
     const u16x2 s2 = __builtin_bit_cast(u16x2, s);
@@ -289,8 +299,8 @@ __device__ __forceinline__ QuadRecord quad_resolve(uint32_t r, bool active, uint
 
 template <bool kLds = false>
 __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
-                                                 uint32_t &bad, uint32_t *match = nullptr) {
-  const QuadRecord q = quad_resolve<CABAC_REC_ALIGN, kLds>(r, active, lane, row, rctx, bad, match);
+                                                 uint32_t &bad, uint32_t *match = nullptr, const uint2 *rates = nullptr) {
+  const QuadRecord q = quad_resolve<CABAC_REC_ALIGN, kLds, kLds>(r, active, lane, row, rctx, bad, match, rates);
   const uint32_t bin = q.bin;
   const uint32_t q8 = ctx2_q8(q.st);
   const uint32_t mps = q8 >> 7;
@@ -339,6 +349,20 @@ __device__ __forceinline__ uint32_t quad_enc_finish(QuadEnc &e, bool align_rbsp,
   const uint32_t n_bits = e.pos * 8u + nb;
   if (nb) quad_put_byte(e, held, writer);
   return n_bits;
+}
+
+// the table quad_resolve<.., kRateTab> reads: per record id {shift0 | shift1 << 16, add0 | add1 << 16} (0 for ids that are no context)
+__device__ __forceinline__ void quad_rate_tab_init(uint2 *tab, uint32_t tid, uint32_t n_threads) {
+  for (uint32_t id = tid; id < 512u; id += n_threads) {
+    uint2 v = make_uint2(0u, 0u);
+    if (id < (uint32_t)kNumCtx) {
+      const uint32_t rates = ctx2_init(0, c_init_tables[id], c_init_tables[3 * kNumCtx + id]) & 31u;
+      const uint32_t r0 = (rates & 3u) + 2u, r1 = ((rates >> 2) & 7u) + 5u;
+      v.x = r0 | (r1 << 16);
+      v.y = ((0x7fffu >> r0) & kMask0) | (((0x7fffu >> r1) & kMask1) << 16);
+    }
+    tab[id] = v;
+  }
 }
 
 __device__ __forceinline__ void quad_ctx_init(uint32_t *rctx, int qp_in, uint32_t iid, uint32_t j) {
@@ -809,10 +833,12 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   __shared__ uint32_t unit_count[U][kRing][kQuadSubs];
   __shared__ uint32_t fin_acc[U][kQuadSubs], fin_rem[U][kQuadSubs];
   __shared__ uint32_t match_all[U][kMatchWords];   // the context waves' same-id bitmaps (quad_resolve)
+  __shared__ uint2 rate_tab[512];
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
   const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: low wave, 3: emit wave
+  quad_rate_tab_init(rate_tab, threadIdx.x, 256u * U);
   // the same-id lanes of the context wave through LDS (quad_resolve): C4 0.85 -> 0.81 ms, C3 16.3 -> 15.8 ms
   constexpr bool kLdsMatch = true;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += 256u * U) (&match_all[0][0])[k] = 0u;
@@ -840,7 +866,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     auto rec_of = [&](uint32_t step) { return (uint32_t)rec_safe[min(16u * step + j, last_rec)]; };
-    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a<kLdsMatch>(r, 16u * step + j < n, lane, row, rctx, bad, match_all[unit]); };
+    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a<kLdsMatch>(r, 16u * step + j < n, lane, row, rctx, bad, match_all[unit], rate_tab); };
     // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
     // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
     uint32_t ahead[4];  // the records of the next four steps
@@ -1071,9 +1097,11 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
   __shared__ uint32_t fin_lo[S], fin_hi[S], fin_pend[S];
   __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
   __shared__ uint32_t match_all[U][kMatchWords];   // the context waves' same-id bitmaps (quad_resolve)
+  __shared__ uint2 rate_tab[512];
   __shared__ uint32_t bad_rows[U];
   __shared__ uint32_t wg_max_n;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  quad_rate_tab_init(rate_tab, threadIdx.x, blockDim.x);
   // same-id lanes of the context waves through LDS (C4 0.81 -> 0.65 ms)
   constexpr bool kLdsMatch = true;
   for (uint32_t k = threadIdx.x; k < U * kMatchWords; k += blockDim.x) (&match_all[0][0])[k] = 0u;
@@ -1147,7 +1175,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
     uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
-    post(0, quad_phase_a<kLdsMatch>(cur_rec, j < n, lane, row, rctx, bad, match_all[unit]));  // step 0
+    post(0, quad_phase_a<kLdsMatch>(cur_rec, j < n, lane, row, rctx, bad, match_all[unit], rate_tab));  // step 0
     __syncthreads();
     for (uint32_t k = 0; k < n_steps; k++) {
       const uint32_t base = 16u * k;
@@ -1157,7 +1185,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       ahead2 = ahead3;
       ahead3 = rec_safe[min(base + 80u + j, last_rec)];
       V5_TICK(t0);
-      post((k + 1u) & 3u, quad_phase_a<kLdsMatch>(r, base + 16u + j < n, lane, row, rctx, bad, match_all[unit]));
+      post((k + 1u) & 3u, quad_phase_a<kLdsMatch>(r, base + 16u + j < n, lane, row, rctx, bad, match_all[unit], rate_tab));
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);

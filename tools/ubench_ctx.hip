@@ -29,14 +29,16 @@ __global__ __launch_bounds__(64) void k_phase(unsigned *out, int iters, unsigned
 __global__ __launch_bounds__(64) void k_phase_lds(unsigned *out, int iters, unsigned seed) {
   __shared__ uint32_t ctx[kQuadSubs * kQuadCtxStride];
   __shared__ uint32_t match[kMatchWords];
+  __shared__ uint2 rate_tab[512];
   const uint32_t lane = threadIdx.x, row = lane >> 4, j = lane & 15u;
   quad_ctx_init(ctx + row * kQuadCtxStride, 32, 2, j);
+  quad_rate_tab_init(rate_tab, lane, 64u);
   for (uint32_t k = lane; k < kMatchWords; k += 64) match[k] = 0;
   __syncthreads();
   unsigned acc = 0, bad = 0;
   for (int i = 0; i < iters; i++) {
     const unsigned r = ((i * 37u + lane * 11u + seed) % 379u) | (((i + lane) & 1u) << 15);
-    acc += quad_phase_a<true>(r, true, lane, row, ctx + row * kQuadCtxStride, bad, match);
+    acc += quad_phase_a<true>(r, true, lane, row, ctx + row * kQuadCtxStride, bad, match, rate_tab);
   }
   out[blockIdx.x * 64 + threadIdx.x] = acc + bad;
 }
