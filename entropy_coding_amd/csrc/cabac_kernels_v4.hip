@@ -727,14 +727,18 @@ __device__ __forceinline__ uint64_t shl64(uint32_t lo, uint32_t hi, uint32_t n) 
 // The code value of one step for the four rows (see above), in two parts.  Part 1 (chain wave, which has the time):
 // lane I picks the twelve bits of its bin out of the row-uniform capture registers, forms (term, shift) and combines four
 // bins at a time: lanes 4m + 3 end up with (value < 2^56, shift) of bins 4m .. 4m + 3.
-__device__ __forceinline__ void quad_low_quads(const QuadRngCap &cap, uint32_t info, uint32_t j, uint32_t &v0, uint32_t &v1,
-                                               uint32_t &s) {
+// this lane's twelve bits (rm | shift << 9 of bin j) out of the row-uniform capture registers
+__device__ __forceinline__ uint32_t quad_cap_mine(const QuadRngCap &cap, uint32_t j) {
   const uint32_t h = j >> 1;
   const uint32_t a0 = (h & 1u) ? cap.w[1] : cap.w[0], a1 = (h & 1u) ? cap.w[3] : cap.w[2], a2 = (h & 1u) ? cap.w[5] : cap.w[4],
                  a3 = (h & 1u) ? cap.w[7] : cap.w[6];
   const uint32_t b0 = (h & 2u) ? a1 : a0, b1 = (h & 2u) ? a3 : a2;
   const uint32_t pair = (h & 4u) ? b1 : b0;
-  const uint32_t w12 = (j & 1u) ? pair >> 16 : pair;
+  return ((j & 1u) ? pair >> 16 : pair) & 0xfffu;
+}
+
+// (term, shift) of the lane's bin and the first two tree levels: lanes 4m + 3 end up with (value < 2^56, shift) of bins 4m .. 4m + 3
+__device__ __forceinline__ void quad_low_quads12(uint32_t w12, uint32_t info, uint32_t &v0, uint32_t &v1, uint32_t &s) {
   const uint32_t rm = w12 & 0x1ffu, nb = (w12 >> 9) & 7u;
   const uint32_t lpsm = bit_mask<9>(info), pem = bit_mask<11>(info), ep = (info >> 10) & 1u;
   const uint32_t term = ((rm & lpsm) << nb) | (rm & pem);  // what the bin adds to low after its shift
@@ -753,6 +757,11 @@ __device__ __forceinline__ void quad_low_quads(const QuadRngCap &cap, uint32_t i
   }
   v0 = (uint32_t)v;
   v1 = (uint32_t)(v >> 32);
+}
+
+__device__ __forceinline__ void quad_low_quads(const QuadRngCap &cap, uint32_t info, uint32_t j, uint32_t &v0, uint32_t &v1,
+                                               uint32_t &s) {
+  quad_low_quads12(quad_cap_mine(cap, j), info, v0, v1, s);
 }
 
 // Part 2 (low wave): the four quads and the row's remainder `acc` (9 + rem bits and a possible carry above) -> the five
@@ -827,6 +836,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   // no-ops (no active record, no shift, no unit).
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
   constexpr uint32_t kRing = 2 * kSync;         // steps in flight between two neighbouring roles
+  constexpr bool kTreeInChain = U == 4;         // where the first two levels of the code-value tree run (see the chain wave)
   __shared__ uint32_t mail_all[U][kRing][64];
   __shared__ uint32_t quad_post[U][kRing][3][64];  // chain -> low: per lane (value low, value high, shift) of its four-bin segment
   __shared__ uint32_t unit_list[U][kRing][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
@@ -916,11 +926,16 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
         QuadRngCap cap;
         if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
         else quad_rng_steps<true>(f, range, cap);
-        uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
-        quad_low_quads(cap, info, j, q0, q1, qs);
-        quad_post[unit][slot][0][lane] = q0;
-        quad_post[unit][slot][1][lane] = q1;
-        quad_post[unit][slot][2][lane] = qs;
+        if (kTreeInChain) {
+          uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
+          quad_low_quads(cap, info, j, q0, q1, qs);
+          quad_post[unit][slot][0][lane] = q0;
+          quad_post[unit][slot][1][lane] = q1;
+          quad_post[unit][slot][2][lane] = qs;
+        } else {                // one unit per workgroup: every wave has a SIMD to itself and this one is the longest
+          quad_post[unit][slot][0][lane] = quad_cap_mine(cap, j);
+          quad_post[unit][slot][1][lane] = info;
+        }
       }
       V5_TICK(t1);
       __syncthreads();
@@ -937,8 +952,10 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     auto list_step = [&](uint32_t step) {
       const uint32_t slot = step & (kRing - 1u);
       uint32_t w[5];
-      const uint32_t s_total = quad_low_join(quad_post[unit][slot][0][lane], quad_post[unit][slot][1][lane],
-                                             quad_post[unit][slot][2][lane], acc, j, w);
+      uint32_t q0 = quad_post[unit][slot][0][lane], q1 = quad_post[unit][slot][1][lane], qs;
+      if (kTreeInChain) qs = quad_post[unit][slot][2][lane];
+      else quad_low_quads12(q0, q1, q0, q1, qs);
+      const uint32_t s_total = quad_low_join(q0, q1, qs, acc, j, w);
       const uint32_t pendn = rem + s_total, m = pendn >> 4;  // whole units in this step: at most 7
       rem = pendn & 15u;
       const uint32_t base_off = 9u + rem;
