@@ -34,7 +34,7 @@ DESC_BYTES, RESULT_BYTES = 32, 8
 
 def kernel_names(enc_variant, dec_variant, n_sub):
     """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
-    enc = {1: "v1", 2: "v2", 3: "v3", 4: "v4", 5: "v5", 6: "v6", 7: "v7"}.get(enc_variant & 0xFF, "v7" if n_sub >= 2048 else "v6")
+    enc = {1: "v1", 2: "v2", 3: "v3", 4: "v4", 5: "v5", 6: "v6", 7: "v7"}.get(enc_variant & 0xFF, "v7" if n_sub >= 3072 else "v6")
     dec = {1: "v1", 2: "v2", 3: "v3"}.get(dec_variant & 0xFF, "v4")
     return "encode_kernel_" + enc, "decode_kernel_" + dec
 

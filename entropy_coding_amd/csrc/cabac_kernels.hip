@@ -1156,11 +1156,10 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  // auto (measured, DESIGN.md §3, tools/enc_scaling.py): from 2 048 substreams the lane-serial encoder (v7: 2 048 substreams 0.64,
-  // C4 0.64, C5 10.3 ms, 16 384 substreams 1.90 ms against v6's 0.70 / 0.80 / 12.2 / 2.81); below, one unit per workgroup and
-  // at most one workgroup per CU, the four-wave quad encoder (v6: C2 0.69, C3 14.5 ms, 1 024 substreams 0.48 ms against v7's
-  // 0.78 / 16.5 / 0.65)
-  if (kind == 7 || (kind == 0 && max(n_sub, in_flight) >= 2048u)) return launch_encode_v7(st, n_sub, desc, records, bytes, results, in_flight);
+  // auto (measured, DESIGN.md §3, tools/enc_scaling.py): from 3 072 substreams the lane-serial encoder (v7: C4 0.64, C5 10.3 ms,
+  // 16 384 substreams 1.90 ms against v6's 0.82 / 12.8 / 2.81); below, one unit per workgroup, the four-wave quad encoder (v6:
+  // C2 0.61, C3 12.8 ms, 1 024 substreams 0.43, 2 048: 0.57 ms against v7's 0.78 / 16.5 / 0.65 / 0.64)
+  if (kind == 7 || (kind == 0 && max(n_sub, in_flight) >= 3072u)) return launch_encode_v7(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 6 || kind == 0) return launch_encode_v6(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 5) return launch_encode_v5(st, n_sub, desc, records, bytes, results, in_flight);
   if (kind == 4) return launch_encode_v4(st, n_sub, desc, records, bytes, results);

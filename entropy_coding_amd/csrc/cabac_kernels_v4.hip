@@ -66,6 +66,27 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x) {
 __device__ __forceinline__ uint32_t sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 __device__ __forceinline__ uint32_t neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }  // ~0 if bit 31 set
 
+// sixteen consecutive LDS words into registers, four at a time (16-byte reads)
+__device__ __forceinline__ void lds_read4(const uint32_t *p, int q, uint32_t (&dst)[16]) {
+  const uint4 v = reinterpret_cast<const uint4 *>(p)[q];
+  dst[4 * q] = v.x;
+  dst[4 * q + 1] = v.y;
+  dst[4 * q + 2] = v.z;
+  dst[4 * q + 3] = v.w;
+}
+__device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&dst)[16]) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint4 v = q[i];
+    dst[4 * i] = v.x;
+    dst[4 * i + 1] = v.y;
+    dst[4 * i + 2] = v.z;
+    dst[4 * i + 3] = v.w;
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // encode
 
@@ -714,6 +735,31 @@ __device__ __forceinline__ void quad_rng_step(const QuadEncInfo &f, uint32_t &ra
   else cap.w[I >> 1] = w;
 }
 
+// the same with the row-uniform fields of the 16 bins in registers (read back from LDS, where lane I parked bin I's: an
+// LDS read of one address by all lanes of a row is the broadcast — three v_mov_b32_dpp per bin less, see QuadDecRow)
+struct QuadEncRow {
+  uint32_t k[16], c2[16], lpsm[16];
+};
+template <int I, bool kAlign>
+__device__ __forceinline__ void quad_rng_step_row(const QuadEncRow &u, const QuadEncInfo &f, uint32_t &range, QuadRngCap &cap) {
+  const uint32_t t = (__umul24((range >> 5) & 15u, u.k[I]) + u.c2[I]) >> 1;  // LPS width: ((r>>5)*k>>1) + c
+  const uint32_t rm = range - t;
+  const uint32_t x = sel(u.lpsm[I], t, rm);
+  const uint32_t nb = (uint32_t)(__builtin_clz(x) - 23);
+  range = x << nb;
+  if (kAlign) range = sel(row_bcast<I>(f.alm), 256u, range);
+  const uint32_t w = rm | (nb << 9);
+  if (I & 1) cap.w[I >> 1] |= w << 16;
+  else cap.w[I >> 1] = w;
+}
+template <bool kAlign>
+__device__ __forceinline__ void quad_rng_steps_row(const QuadEncRow &u, const QuadEncInfo &f, uint32_t &range, QuadRngCap &cap) {
+#define QSTEP(I) quad_rng_step_row<I, kAlign>(u, f, range, cap)
+  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
+  QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+#undef QSTEP
+}
+
 template <bool kAlign>
 __device__ __forceinline__ void quad_rng_steps(const QuadEncInfo &f, uint32_t &range, QuadRngCap &cap) {
 #define QSTEP(I) quad_rng_step<I, kAlign>(f, range, cap)
@@ -837,7 +883,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
   constexpr uint32_t kRing = 2 * kSync;         // steps in flight between two neighbouring roles
   constexpr bool kTreeInChain = U == 4;         // where the first two levels of the code-value tree run (see the chain wave)
-  __shared__ uint32_t mail_all[U][kRing][64];
+  __shared__ __attribute__((aligned(16))) uint32_t mail_all[U][kRing][4][64];   // context -> chain: per bin the packed word, k, 2c, the LPS mask
   __shared__ uint32_t quad_post[U][kRing][3][64];  // chain -> low: per lane (value low, value high, shift) of its four-bin segment
   __shared__ uint32_t unit_list[U][kRing][kQuadSubs][kUnitSlots];  // low -> emit: the units of a step, first with its carry
   __shared__ uint32_t unit_count[U][kRing][kQuadSubs];
@@ -856,7 +902,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
   const uint32_t n = live ? d.n_records : 0u;
-  uint32_t (*mail)[64] = mail_all[unit];
+  uint32_t (*mail)[4][64] = mail_all[unit];
 
   if (threadIdx.x == 0) wg_max_n = 0;
   __syncthreads();
@@ -876,7 +922,14 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     auto rec_of = [&](uint32_t step) { return (uint32_t)rec_safe[min(16u * step + j, last_rec)]; };
-    auto phase = [&](uint32_t step, uint32_t r) { mail[step & (kRing - 1u)][lane] = quad_phase_a<kLdsMatch>(r, 16u * step + j < n, lane, row, rctx, bad, match_all[unit], rate_tab); };
+    auto phase = [&](uint32_t step, uint32_t r) {
+      const uint32_t info = quad_phase_a<kLdsMatch>(r, 16u * step + j < n, lane, row, rctx, bad, match_all[unit], rate_tab);
+      uint32_t (*m)[64] = mail[step & (kRing - 1u)];
+      m[0][lane] = info;
+      m[1][lane] = info & 31u;
+      m[2][lane] = (info >> 5) & 15u;
+      m[3][lane] = bit_mask<9>(info);
+    };
     // records are fetched four steps ahead: a step is shorter than a trip to HBM (measured: with one step of lead this
     // wave waited ~1 400 cycles per step for its load and was what every other wave of the unit waited for)
     uint32_t ahead[4];  // the records of the next four steps
@@ -921,11 +974,19 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
 #pragma unroll
       for (uint32_t h = 0; h < kSync; h++) {
         const uint32_t slot = (kSync * it + h) & (kRing - 1u);
-        const uint32_t info = mail[slot][lane];
-        const QuadEncInfo f = quad_unpack(info);
+        const uint32_t info = mail[slot][0][lane];
+        QuadEncRow u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {   // in bin order, so that the first four bins only wait for the first three reads
+          lds_read4(&mail[slot][1][row * 16u], q, u.k);
+          lds_read4(&mail[slot][2][row * 16u], q, u.c2);
+          lds_read4(&mail[slot][3][row * 16u], q, u.lpsm);
+        }
+        QuadEncInfo f;
+        f.alm = bit_mask<12>(info);
         QuadRngCap cap;
-        if (__ballot(info >> 12) == 0) quad_rng_steps<false>(f, range, cap);
-        else quad_rng_steps<true>(f, range, cap);
+        if (__ballot(info >> 12) == 0) quad_rng_steps_row<false>(u, f, range, cap);
+        else quad_rng_steps_row<true>(u, f, range, cap);
         if (kTreeInChain) {
           uint32_t q0, q1, qs;  // the first two levels of the code-value tree are done here, where there is time
           quad_low_quads(cap, info, j, q0, q1, qs);
@@ -1078,25 +1139,6 @@ __device__ __forceinline__ uint32_t lane_rng_step(uint32_t k, uint32_t c2, uint3
   range = x << nb;
   if (kAlign) range = sel(alm, 256u, range);
   return rm | (nb << 9);
-}
-
-__device__ __forceinline__ void lds_read4(const uint32_t *p, int q, uint32_t (&dst)[16]) {
-  const uint4 v = reinterpret_cast<const uint4 *>(p)[q];
-  dst[4 * q] = v.x;
-  dst[4 * q + 1] = v.y;
-  dst[4 * q + 2] = v.z;
-  dst[4 * q + 3] = v.w;
-}
-__device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&dst)[16]) {
-  const uint4 *q = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint4 v = q[i];
-    dst[4 * i] = v.x;
-    dst[4 * i + 1] = v.y;
-    dst[4 * i + 2] = v.z;
-    dst[4 * i + 3] = v.w;
-  }
 }
 
 template <int U>
