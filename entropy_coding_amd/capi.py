@@ -55,7 +55,8 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = ctypes.CDLL(build_library())
+    # CABAC_HIP_LIBRARY: load this build of the library instead (experiments: the same sources under other compiler flags)
+    L = ctypes.CDLL(os.environ.get("CABAC_HIP_LIBRARY") or build_library())
     L.cabac_hip_encode_bound.restype = ctypes.c_size_t
     L.cabac_hip_encode_bound.argtypes = [ctypes.c_uint64] * 3
     L.cabac_hip_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
