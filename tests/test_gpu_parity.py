@@ -327,7 +327,7 @@ import sys, numpy as np
 sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
 import helpers as H
 from entropy_coding_amd import capi
-hip = capi.CabacHip(0); hip.set_variant(5, 0)
+hip = capi.CabacHip(0); hip.set_variant(%(enc)d, 0)
 orc = H.load_oracle()
 rng = np.random.default_rng(4242)
 # ragged lengths incl. empty and single-record substreams, a too small buffer and a bad record, in one batch that
@@ -375,6 +375,18 @@ def test_v5_units_per_workgroup_on_ragged_batches(units):
     import subprocess
     import sys
     env = dict(os.environ, CABAC_V5_UNITS=str(units))
-    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT}
+    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT, "enc": 5}
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("enc", [0, 6, 7])
+def test_ragged_batches_above_and_below_the_big_batch_geometries(enc):
+    """The same ragged batches (37 and 4 100 substreams: empty and one-record substreams, a bad record, a buffer that is too
+    small, an incomplete last workgroup) through the dispatched encoders: 4 100 substreams take the 16-substream workgroups
+    of v7 (auto, 7) and the four-unit workgroups of v6 (6), 37 the one-unit workgroups."""
+    import subprocess
+    import sys
+    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT, "enc": enc}
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
