@@ -332,6 +332,28 @@ __device__ __forceinline__ uint32_t quad_phase_a(uint32_t r, bool active, uint32
          ((1u << 12) & q.alnm);
 }
 
+// The same as separate words for the lane-serial encoder (v7), which parks them in LDS field by field: no packing here and
+// no unpacking there.
+struct QuadFields {
+  uint32_t k, c2, lpsm, lp9, ep, alm;
+};
+template <bool kLds = false>
+__device__ __forceinline__ QuadFields quad_phase_fields(uint32_t r, bool active, uint32_t lane, uint32_t row, uint32_t *rctx,
+                                                        uint32_t &bad, uint32_t *match = nullptr, const uint2 *rates = nullptr) {
+  const QuadRecord q = quad_resolve<CABAC_REC_ALIGN, kLds, kLds>(r, active, lane, row, rctx, bad, match, rates);
+  const uint32_t sum = (q.st & kMask0) + (q.st >> 16);            // state(), contexts.cpp:939-950
+  const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);     // 0 / ~0: the MPS
+  const uint32_t binm = 0u - q.bin;                               // 0 / ~0: the bin
+  QuadFields f;
+  f.k = ((sum >> 10) ^ sx) & 31u & q.ctxm;
+  f.c2 = (8u & q.ctxm) | (4u & q.trmm);                           // terminate == LPS width 2 (arith_codec.cpp:460-478)
+  f.lpsm = ((binm ^ sx) & q.ctxm) | (binm & q.trmm);              // the LPS path: bin != MPS, or a terminate bin 1
+  f.lp9 = (f.lpsm | (binm & q.epm)) & 0x1ffu;                     // the bin adds its MPS sub-range to low: LPS, or a bypass bin 1
+  f.ep = q.epm & 1u;
+  f.alm = q.alnm;
+  return f;
+}
+
 __device__ __forceinline__ QuadEncInfo quad_unpack(uint32_t info) {
   QuadEncInfo f;
   f.k = info & 31u;
@@ -1222,19 +1244,18 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
     const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
     const uint32_t last_rec = n != 0 ? n - 1u : 0u;
     const uint32_t at = local * kV7Pad + j;
-    auto post = [&](uint32_t slot, uint32_t info) {
-      const uint32_t lpsm = bit_mask<9>(info), pem = bit_mask<11>(info);
-      fld[slot][kV7K][at] = info & 31u;
-      fld[slot][kV7C2][at] = (info >> 5) & 15u;
-      fld[slot][kV7Lpsm][at] = lpsm;
-      fld[slot][kV7Lp9][at] = (lpsm | pem) & 0x1ffu;   // the bin adds its MPS sub-range to low: LPS, or a bypass bin 1
-      fld[slot][kV7Ep][at] = (info >> 10) & 1u;
-      fld[slot][kV7Alm][at] = bit_mask<12>(info);
+    auto post = [&](uint32_t slot, const QuadFields &f) {
+      fld[slot][kV7K][at] = f.k;
+      fld[slot][kV7C2][at] = f.c2;
+      fld[slot][kV7Lpsm][at] = f.lpsm;
+      fld[slot][kV7Lp9][at] = f.lp9;
+      fld[slot][kV7Ep][at] = f.ep;
+      fld[slot][kV7Alm][at] = f.alm;
     };
     const uint32_t cur_rec = rec_safe[min(j, last_rec)];
     uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
     uint32_t ahead1 = rec_safe[min(32u + j, last_rec)], ahead2 = rec_safe[min(48u + j, last_rec)], ahead3 = rec_safe[min(64u + j, last_rec)];
-    post(0, quad_phase_a<kLdsMatch>(cur_rec, j < n, lane, row, rctx, bad, match_all[unit], rate_tab));  // step 0
+    post(0, quad_phase_fields<kLdsMatch>(cur_rec, j < n, lane, row, rctx, bad, match_all[unit], rate_tab));  // step 0
     __syncthreads();
     for (uint32_t k = 0; k < n_steps; k++) {
       const uint32_t base = 16u * k;
@@ -1244,7 +1265,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
       ahead2 = ahead3;
       ahead3 = rec_safe[min(base + 80u + j, last_rec)];
       V5_TICK(t0);
-      post((k + 1u) & 3u, quad_phase_a<kLdsMatch>(r, base + 16u + j < n, lane, row, rctx, bad, match_all[unit], rate_tab));
+      post((k + 1u) & 3u, quad_phase_fields<kLdsMatch>(r, base + 16u + j < n, lane, row, rctx, bad, match_all[unit], rate_tab));
       V5_TICK(t1);
       __syncthreads();
       V5_TICK(t2);
