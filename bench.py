@@ -39,6 +39,24 @@ def kernel_names(enc_variant, dec_variant, n_sub):
     return "encode_kernel_" + enc, "decode_kernel_" + dec
 
 
+def vector_issue(workload, kernel, kernel_ms):
+    """What the kernel does against the roof that binds it: the vector instructions one launch executes
+    (SQ counters of the committed profile run of THIS workload, profiles/r02_sq_instruction_mix.txt) over the chip's vector
+    issue rate, 1024 SIMDs x one wave-wide instruction per ~2 ns (tools/ubench_mix.hip).  None without the profile."""
+    if workload != "C4":
+        return None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_sq_instruction_mix.txt")):
+            if line.split("<")[0].strip() == kernel:
+                valu = float(line.split("VALU")[1].split()[0])
+                floor_ms = valu / (1024 * 0.5e9) * 1e3
+                return {"valu_instructions_per_launch": valu, "peak_ginstr_s": 512.0, "floor_ms": round(floor_ms, 4),
+                        "frac": round(floor_ms / kernel_ms, 4), "source": "profiles/r02_sq_instruction_mix.txt (replayed, not live)"}
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def measured_traffic(workload, kernel):
     """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json), or None."""
     try:
@@ -662,6 +680,7 @@ def main():
                 "bound": "hbm",        # the roof the tier prices against; what limits these kernels is in `limiter`
                 "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD issues one instruction per ~2 ns: ~640 per 16-bin decode step); HBM traffic equals the algorithmic bytes",
                 "kernel": k_dom,
+                "vector_issue": vector_issue(cfg.name, k_dom, dec_avg if dominant == "decode" else enc_avg),
                 "achieved": round(ach, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
