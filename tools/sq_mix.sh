@@ -18,7 +18,7 @@ for sub in ("a", "b"):
             d = acc.setdefault(k, {})
             d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 for k, d in sorted(acc.items()):
-    last = {c: v[-1] for c, v in d.items()}
+    last = {c: v[0] for c, v in d.items()}   # the first launch of a kernel: the C4 batch of the timed region (later ones: the residual legs)
     print("%-40s " % k + "  ".join("%s %.3g" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), last[c]) for c in sorted(last)))
 PY
 cat "$OUT/mix.txt"
