@@ -123,7 +123,8 @@ typedef struct cabac_substream_result {
 #define CABAC_RES_OVERFLOW 0x1u    /* encode: byte_capacity too small (output truncated)     */
 #define CABAC_RES_BAD_RECORD 0x2u  /* record id is neither a ctxId < 379 nor a special id    */
 #define CABAC_RES_UNDERRUN 0x4u    /* decode: read past byte_capacity ("FIFO exceeded",      \
-                                      bit_stream.cpp:269)                                    */
+                                      bit_stream.cpp:269: the reference throws there); the   \
+                                      bins from that read on and n_bits are unspecified      */
 #define CABAC_RES_BAD_STOP 0x8u    /* decode: finish() stop/alignment pattern check failed   */
 
 typedef enum cabac_hip_status {
