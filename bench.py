@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--no-residual", action="store_true", help="skip the residual-binariser leg (C4, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--no-co-scheduled", action="store_true", help="skip the two-stream (encode beside decode) leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -170,6 +171,63 @@ def cpu_baseline(cfg, desc, records, budget_s):
         "one_thread": {"value": round(2 * bins1 / (enc1 + dec1) / 1e6, 2), "cores": 1,
                        "encode_mbins_s": round(bins1 / enc1 / 1e6, 2), "decode_mbins_s": round(bins1 / dec1 / 1e6, 2)},
     }
+
+
+def co_scheduled_leg(local_rank, variants, n_sub, n_bins, n_slots, t_desc, t_rec, bytes_total, want_bins, steps, warmup):
+    """The same step — one encode and one decode of the whole resident batch — with the two kernels on two streams: the
+    decode of step k (reading what the encode of step k wrote, after its event) runs beside the encode of step k + 1
+    (into the other of two byte buffers, after the decode that last read it).  On the headline batch either kernel alone
+    leaves issue slots of the SIMDs unused (decode: one wave per SIMD); together they fill them.  Not `value`: the
+    per-kernel durations the roofline is computed from are only meaningful when a kernel has the chip to itself."""
+    import torch
+    from entropy_coding_amd import capi
+    s_enc, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+    h_enc = capi.CabacHip(local_rank, stream=s_enc.cuda_stream)
+    h_dec = capi.CabacHip(local_rank, stream=s_dec.cuda_stream)
+    h_enc.set_variant(*variants)
+    h_dec.set_variant(*variants)
+    bufs = [torch.zeros(max(bytes_total, 16), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    res_e = [torch.zeros(max(n_sub, 1) * 2, dtype=torch.int32, device="cuda") for _ in range(2)]
+    res_d = torch.zeros(max(n_sub, 1) * 2, dtype=torch.int32, device="cuda")
+    bins = torch.zeros(max(n_slots, 1), dtype=torch.uint8, device="cuda")
+    coded = [torch.cuda.Event() for _ in range(2)]
+    read = [torch.cuda.Event() for _ in range(2)]
+    torch.cuda.synchronize()
+    k = 0
+
+    def step():
+        nonlocal k
+        b = k & 1
+        if k >= 2:
+            s_enc.wait_event(read[b])            # the decode of step k - 2 has finished with this buffer
+        h_enc.encode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), bufs[b].data_ptr(), res_e[b].data_ptr())
+        coded[b].record(s_enc)
+        s_dec.wait_event(coded[b])
+        h_dec.decode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), bufs[b].data_ptr(), bins.data_ptr(), res_d.data_ptr())
+        read[b].record(s_dec)
+        k += 1
+
+    for _ in range(warmup + 2):
+        step()
+    torch.cuda.synchronize()
+    h_enc.profile_enable(steps)
+    h_dec.profile_enable(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    enc_ms = float(np.mean([m for kk, m in h_enc.profile_read() if kk == 0]))
+    dec_ms = float(np.mean([m for kk, m in h_dec.profile_read() if kk == 1]))
+    ok = (not bool(res_d.view(-1, 2)[:, 1].any().item()) and not bool(res_e[0].view(-1, 2)[:, 1].any().item())
+          and not bool(res_e[1].view(-1, 2)[:, 1].any().item()) and bool(torch.equal(bins[:n_slots], want_bins))
+          and bool(torch.equal(bufs[0], bufs[1])))
+    h_enc.close()
+    h_dec.close()
+    return {"mbins_s": round(2 * n_bins / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4), "steps": steps, "round_trip": ok,
+            "kernel_ms_while_sharing_the_chip": {"encode": round(enc_ms, 4), "decode": round(dec_ms, 4)},
+            "what": "encode and decode of the batch on two streams (decode of step k beside the encode of step k + 1, "
+                    "double-buffered bytes, event-ordered); wall time per step"}
 
 
 def end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins, reps=3):
@@ -719,6 +777,12 @@ def main():
                               "gather_ms": None if gather_ms_strong is None else round(gather_ms_strong, 3),
                               "scatter_bytes": 2 * bins_all, "gathered_payload_bytes": total_payload,
                               "what": "scatter / gather are outside the timed region: the step is encode + decode of the resident shard"}
+        if world == 1 and not args.no_co_scheduled and not args.strong:
+            try:
+                line["co_scheduled"] = co_scheduled_leg(local_rank, (args.enc_variant, args.dec_variant), n_sub, n_bins, n_slots,
+                                                        t_desc, t_rec, bytes_total, want_bins, args.steps, args.warmup)
+            except Exception as e:
+                line["co_scheduled"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_end_to_end and not args.strong:
             try:
                 line["end_to_end"] = end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins)
