@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 BENCH="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end"
 python3 $BENCH > "$OUT/bench_line.json" 2> "$OUT/bench_line.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || exit 2
-MAIN="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-residual"   # the timed kernels only
+MAIN="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-residual --no-co-scheduled"   # the timed kernels only
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_main" -o run -- python3 $MAIN > "$OUT/bench_main_under_rocprof.json" 2> "$OUT/stats_main.err" || exit 5
 find "$OUT/stats_main" -name "*kernel_stats.csv" -exec cp {} "$OUT/main_kernel_stats.csv" \;
 rm -rf "$OUT/stats_main"
-SHORT="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end"
+SHORT="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-co-scheduled"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 $SHORT > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python3 $SHORT > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || exit 4
 # keep what is small enough to travel back: the stats summary and the per-dispatch counter rows of our kernels

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/sq_mix
 mkdir -p "$OUT"
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-co-scheduled"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/a" -o run -- python3 $BENCH > "$OUT/a.json" 2> "$OUT/a.err" || exit 1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH --kernel-trace --output-format csv -d "$OUT/b" -o run -- python3 $BENCH > "$OUT/b.json" 2> "$OUT/b.err" || exit 2
 python3 - "$OUT" <<'PY' > "$OUT/mix.txt"
