@@ -2,6 +2,7 @@
 import ctypes
 import sys
 import os
+import weakref
 
 import numpy as np
 
@@ -35,11 +36,27 @@ EXPORTS = [
     "cabac_hip_assemble_device", "cabac_hip_split_device", "cabac_hip_count_emulations_device",
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
-    "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload",
+    "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload", "cabac_hip_wait_event", "cabac_hip_record_event",
 ]
 
 _lib = None
 vp = ctypes.c_void_p
+# every CabacHip / PinnedArray that has not been closed yet: close_all() ends them in a defined order (contexts first, then
+# the pinned buffers they may still have been copying from) while the HIP runtime is certainly alive
+_live = weakref.WeakSet()
+
+
+def close_all():
+    """Close every live context, then every live pinned array.  Call before the process ends (a test session's last
+    fixture, a server's shutdown hook): teardown then happens here, in this order, and not in whatever order the
+    interpreter and the loaded libraries are finalized in."""
+    objs = list(_live)
+    for o in objs:
+        if isinstance(o, CabacHip):
+            o.close()
+    for o in objs:
+        if isinstance(o, PinnedArray):
+            o.close()
 
 
 def load_library():
@@ -68,6 +85,8 @@ def load_library():
     L.cabac_hip_last_error.argtypes = [vp]
     L.cabac_hip_set_stream.argtypes = [vp, vp]
     L.cabac_hip_synchronize.argtypes = [vp]
+    L.cabac_hip_wait_event.argtypes = [vp, vp]
+    L.cabac_hip_record_event.argtypes = [vp, vp]
     L.cabac_hip_set_variant.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.cabac_hip_encode_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp]
     L.cabac_hip_decode_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
@@ -127,6 +146,7 @@ class PinnedArray:
         if rc != 0:
             raise CabacHipError(rc, "cabac_hip_host_alloc(%d)" % n)
         self._p = p
+        _live.add(self)
         buf = (ctypes.c_uint8 * max(n, 1)).from_address(p.value)
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
@@ -135,6 +155,7 @@ class PinnedArray:
             self.array = None
             load_library().cabac_hip_host_free(self._p)
             self._p = None
+            _live.discard(self)
 
     def __del__(self):
         # not while the interpreter is shutting down: the HIP runtime (torch's, ours) may already be unloading then, and a
@@ -166,13 +187,15 @@ class CabacHip:
             raise CabacHipError(rc, "cabac_hip_init(device=%d)" % device)
         self.h = h
         self.device = device
+        _live.add(self)
         if stream is not None:
             self._check(self.L.cabac_hip_set_stream(self.h, vp(stream)))
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.cabac_hip_destroy(self.h)
+            self.L.cabac_hip_destroy(self.h)   # waits for the ctx's streams, then releases them
             self.h = None
+            _live.discard(self)
 
     def __del__(self):
         # not while the interpreter is shutting down: the HIP runtime (torch's, ours) may already be unloading then, and a
@@ -193,6 +216,13 @@ class CabacHip:
 
     def synchronize(self):
         self._check(self.L.cabac_hip_synchronize(self.h))
+
+    def wait_event(self, hip_event):
+        """The ctx's stream waits for `hip_event` (a hipEvent_t, e.g. torch.cuda.Event(...).cuda_event after record())."""
+        self._check(self.L.cabac_hip_wait_event(self.h, vp(hip_event)))
+
+    def record_event(self, hip_event):
+        self._check(self.L.cabac_hip_record_event(self.h, vp(hip_event)))
 
     def last_kernel_ms(self):
         return float(self.L.cabac_hip_last_kernel_ms(self.h))

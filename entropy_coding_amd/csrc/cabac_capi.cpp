@@ -154,15 +154,55 @@ bool host_is_pinned(const void *p, size_t bytes) {
         if (q >= b && q + bytes <= b + kv.second) return true;
       }
   }
-  hipPointerAttribute_t a;  // pinned by somebody else (e.g. torch's pin_memory)
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+  // pinned by somebody else (e.g. torch's pin_memory): the first AND the last byte must be host memory the runtime knows, inside
+  // ONE allocation whose extent the runtime can tell — a range that starts in a pinned allocation and runs past its end, or
+  // whose end cannot be established, is treated as pageable (it then goes through the bounce ring, which is always safe)
+  const uint8_t *q = static_cast<const uint8_t *>(p);
+  hipPointerAttribute_t a, z;
+  if (hipPointerGetAttributes(&a, q) != hipSuccess || hipPointerGetAttributes(&z, q + (bytes ? bytes - 1 : 0)) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  return a.type == hipMemoryTypeHost;
+  if (a.type != hipMemoryTypeHost || z.type != hipMemoryTypeHost) return false;
+  hipDeviceptr_t base = nullptr;
+  size_t extent = 0;
+  if (hipMemGetAddressRange(&base, &extent, const_cast<uint8_t *>(q)) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  const uint8_t *b = static_cast<const uint8_t *>(base);
+  return q >= b && q + bytes <= b + extent;
+}
+
+// Nothing of the ctx's own streams is in flight afterwards and no bounce block is waiting to be handed over: the state a
+// host-pointer call must leave behind when it returns early (the blocks' destinations point into the caller's buffers,
+// which the caller may free as soon as the call has returned — they are dropped, not copied).
+void pipe_quiesce(cabac_hip_ctx *c) {
+  for (hipStream_t st : {c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
+    if (st) (void)hipStreamSynchronize(st);
+  for (cabac_hip_ctx::Bounce *b : {&c->bounce_in, &c->bounce_out})
+    for (int i = 0; i < cabac_hip_ctx::kBounceDepth; i++) {
+      b->busy[i] = false;
+      b->dst[i] = nullptr;
+      b->len[i] = 0;
+    }
+}
+
+// the exit of every host-pointer entry point: an error other than "a substream has a flag set" may have come from the middle
+// of the pipeline
+int host_call_exit(cabac_hip_ctx *c, int rc) {
+  if (c && c->pipe_ready && rc != CABAC_HIP_OK && rc != CABAC_HIP_ERR_SUBSTREAM) {
+    const std::string keep = c->last_error;
+    DeviceGuard g(c->device);
+    pipe_quiesce(c);
+    (void)hipGetLastError();
+    c->last_error = keep;
+  }
+  return rc;
 }
 
 void pipe_destroy(cabac_hip_ctx *c) {
+  pipe_quiesce(c);
   for (hipStream_t st : {c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
     if (st) (void)hipStreamDestroy(st);
   for (int i = 0; i < cabac_hip_ctx::kMaxChunks; i++)
@@ -417,6 +457,20 @@ int cabac_hip_set_stream(cabac_hip_ctx *c, void *hip_stream) {
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_wait_event(cabac_hip_ctx *c, void *hip_event) {
+  if (!c || !hip_event) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
+  return CABAC_HIP_OK;
+}
+
+int cabac_hip_record_event(cabac_hip_ctx *c, void *hip_event) {
+  if (!c || !hip_event) return CABAC_HIP_ERR_INVALID;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipEventRecord((hipEvent_t)hip_event, c->stream));
+  return CABAC_HIP_OK;
+}
+
 int cabac_hip_synchronize(cabac_hip_ctx *c) {
   if (!c) return CABAC_HIP_ERR_INVALID;
   DeviceGuard g(c->device);
@@ -668,7 +722,7 @@ static int encode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
 int cabac_hip_encode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                            uint64_t n_records_total, uint8_t *bytes, uint64_t bytes_total,
                            cabac_substream_result *results) {
-  return encode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, nullptr, 0, nullptr, results);
+  return host_call_exit(c, encode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, nullptr, 0, nullptr, results));
 }
 
 int cabac_hip_encode_batch_payload(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
@@ -677,8 +731,8 @@ int cabac_hip_encode_batch_payload(cabac_hip_ctx *c, uint32_t n_sub, const cabac
   if (!payload || !payload_offsets) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   uint64_t slots_end = 0;  // the device-side slots still follow the descriptors' byte_offset / byte_capacity
   for (uint32_t s = 0; s < n_sub && desc; s++) slots_end = std::max<uint64_t>(slots_end, desc[s].byte_offset + desc[s].byte_capacity);
-  return encode_batch_impl(c, n_sub, desc, records, n_records_total, nullptr, slots_end, payload, payload_capacity,
-                           payload_offsets, results);
+  return host_call_exit(c, encode_batch_impl(c, n_sub, desc, records, n_records_total, nullptr, slots_end, payload, payload_capacity,
+                                             payload_offsets, results));
 }
 
 int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
@@ -715,9 +769,9 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
   return status;
 }
 
-int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                           uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
-                           cabac_substream_result *results) {
+static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                             uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
+                             cabac_substream_result *results) {
   if (!c || (n_sub && (!desc || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   if (n_sub == 0) return CABAC_HIP_OK;
   int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
@@ -773,6 +827,12 @@ int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   }
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
+}
+
+int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                           uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
+                           cabac_substream_result *results) {
+  return host_call_exit(c, decode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, bins, results));
 }
 
 int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t n_sub, const uint64_t *d_se_offset, const uint32_t *d_se,

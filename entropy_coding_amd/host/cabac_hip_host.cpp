@@ -100,16 +100,22 @@ void InputBitstream::peekPreviousByte(uint32_t &byte) {
 }
 
 void InputBitstream::read(uint32_t uiNumberOfBits, uint32_t &ruiBits) {
-  // MSB-first extraction; the unread part of the last byte stays in m_held_bits (its low m_num_held_bits bits)
+  // MSB-first extraction; the unread part of the last byte stays in m_held_bits (its low m_num_held_bits bits).
+  // Whether the FIFO holds the bytes this read needs is settled BEFORE anything is taken from it, as the reference does
+  // (bit_stream.cpp:240-242): a read that fails leaves the position and the held bits where they were (only the bit
+  // counter has moved, as there).
   if (uiNumberOfBits > 32) fail("Too many bits read");
   m_numBitsRead += uiNumberOfBits;
   uint64_t acc = m_held_bits & ((1u << m_num_held_bits) - 1u);
   uint32_t have = m_num_held_bits;
-  while (have < uiNumberOfBits) {
-    if (m_fifo_idx >= m_fifo.size()) fail("Exceeded FIFO size");
-    m_held_bits = m_fifo[m_fifo_idx++];
-    acc = (acc << 8) | m_held_bits;
-    have += 8;
+  if (uiNumberOfBits > have) {
+    const uint32_t bytes = (uiNumberOfBits - have + 7u) >> 3;  // whole bytes to take: at least one
+    if (uint64_t(m_fifo_idx) + bytes > m_fifo.size()) fail("Exceeded FIFO size");
+    for (uint32_t i = 0; i < bytes; i++) {
+      m_held_bits = m_fifo[m_fifo_idx++];
+      acc = (acc << 8) | m_held_bits;
+    }
+    have += 8 * bytes;
   }
   m_num_held_bits = have - uiNumberOfBits;
   const uint64_t v = acc >> m_num_held_bits;
@@ -137,7 +143,7 @@ uint32_t InputBitstream::readByteAlignment() {
 
 InputBitstream *InputBitstream::extractSubstream(uint32_t uiNumBits) {
   const uint32_t nbytes = uiNumBits / 8;
-  auto *r = new InputBitstream;
+  std::unique_ptr<InputBitstream> r(new InputBitstream);  // a read below may throw
   r->m_fifo.reserve((uiNumBits + 7) >> 3);
   if (m_num_held_bits == 0) {  // byte-aligned source: a plain copy, zero padded past the end of the FIFO
     const uint32_t avail = std::min<uint32_t>(nbytes, uint32_t(m_fifo.size()) - m_fifo_idx);
@@ -148,7 +154,7 @@ InputBitstream *InputBitstream::extractSubstream(uint32_t uiNumBits) {
     for (uint32_t i = 0; i < nbytes; i++) r->m_fifo.push_back(uint8_t(read(8)));
   }
   if (const uint32_t tail = uiNumBits & 7u) r->m_fifo.push_back(uint8_t(read(tail) << (8 - tail)));  // MSB-aligned
-  return r;
+  return r.release();
 }
 
 // ------------------------------------------------------------------ BinCounter

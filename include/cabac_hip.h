@@ -147,11 +147,29 @@ size_t cabac_hip_encode_bound(uint64_t n_ctx_bins, uint64_t n_ep_bins, uint64_t 
 /* device: HIP device ordinal.  Fails (CABAC_HIP_ERR_NO_DEVICE) when no GPU is
  * present: there is no CPU fallback in this library.                         */
 int cabac_hip_init(int device, cabac_hip_ctx **out);
+/* Waits for everything the ctx has in flight (its stream and the copy / kernel streams of the host-pointer entry points),
+ * then releases its streams, events, device staging and pinned bounce blocks.  Call it before the process ends: like any
+ * HIP resource a ctx must not be released from a static destructor or an atexit handler (the runtime may be gone).      */
 void cabac_hip_destroy(cabac_hip_ctx *ctx);
 const char *cabac_hip_strerror(int status);
 const char *cabac_hip_last_error(const cabac_hip_ctx *ctx);
-/* Adopt an existing HIP stream (hipStream_t passed as void*; NULL = ctx's own) */
+/* STREAM ORDERING CONTRACT of the device-pointer entry points (*_device).  They only enqueue work on the ctx's stream and
+ * return.  A ctx starts with a stream of its own, created hipStreamNonBlocking: work on it is NOT ordered after work the
+ * caller has queued elsewhere — not after the null stream either (a hipMemset / hipMemcpyAsync or another library's fill of
+ * the very buffers handed in may still be running) — and the caller's later work is not ordered after it.  Either
+ *   (a) hand the ctx the stream the buffers are produced and consumed on (cabac_hip_set_stream), or
+ *   (b) keep the own stream and order explicitly: record an event behind the producer and cabac_hip_wait_event() it
+ *       before the call; cabac_hip_record_event() an event behind the call and make the consumer's stream wait for it
+ *       (or cabac_hip_synchronize() from the host).
+ * The host-pointer entry points (*_batch) are synchronous: they first wait for the ctx's stream, run on streams of their own
+ * and return when the results are in the caller's memory.
+ *
+ * Adopt an existing HIP stream (hipStream_t passed as void*; NULL = back to a stream of the ctx's own).  The stream stays the
+ * caller's: it must outlive the ctx's use of it and is not destroyed by cabac_hip_destroy.                              */
 int cabac_hip_set_stream(cabac_hip_ctx *ctx, void *hip_stream);
+/* hipStreamWaitEvent(ctx stream, event) / hipEventRecord(event, ctx stream); hipEvent_t passed as void*                 */
+int cabac_hip_wait_event(cabac_hip_ctx *ctx, void *hip_event);
+int cabac_hip_record_event(cabac_hip_ctx *ctx, void *hip_event);
 int cabac_hip_synchronize(cabac_hip_ctx *ctx);
 /* kernel variant: 0 = default (fastest verified), others are listed in DESIGN.md */
 int cabac_hip_set_variant(cabac_hip_ctx *ctx, int encode_variant, int decode_variant);

@@ -360,10 +360,15 @@ long ref_input_bitstream_script(const uint8_t *bytes, long n_bytes, const uint32
   InputBitstream bs;
   bs.getFifo().assign(bytes, bytes + n_bytes);
   long n_sub = 0;
+  bool go_on = false;  // op 10: from here on a throwing step reports 0xFFFFFFFF and the script continues
   for (long i = 0; i < n_steps; i++) {
     const uint32_t op = script[2 * i], arg = script[2 * i + 1];
     try {
       switch (op) {
+      case 7: out[i] = bs.getByteLocation(); break;
+      case 8: out[i] = bs.getNumBitsRead(); break;
+      case 9: out[i] = bs.getHeldBits(); break;
+      case 10: go_on = true; out[i] = 0; break;
       case 0: out[i] = bs.read(arg); break;
       case 1: out[i] = bs.readByte(); break;
       case 2: {
@@ -383,7 +388,7 @@ long ref_input_bitstream_script(const uint8_t *bytes, long n_bytes, const uint32
     } catch (std::exception &ex) {
       strncpy(g_err, ex.what(), sizeof(g_err) - 1);
       out[i] = 0xFFFFFFFFu;
-      return n_sub;
+      if (!go_on) return n_sub;
     }
   }
   return n_sub;

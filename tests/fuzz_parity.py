@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     orc = H.load_oracle()
-    hip = capi.CabacHip(0)
+    hip = H.gpu_ctx()
     t0, rounds, bins = time.time(), 0, 0
     shapes = {}
     while time.time() - t0 < a.seconds:

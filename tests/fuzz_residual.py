@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
-    hip = capi.CabacHip(0)
+    hip = H.gpu_ctx()
     t0, rounds, coeffs = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1_000_003 + rounds

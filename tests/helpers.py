@@ -361,6 +361,16 @@ def load_ref():
     return _ref
 
 
+def gpu_ctx(device=0):
+    """A codec context for tests that hand torch tensors to the device-pointer entry points: it runs on torch's current
+    stream, so the library's launches are ordered after torch's fills of those tensors and torch's reads after the launches
+    (cabac_hip.h, stream ordering contract, form (a)).  tests/test_gpu_two_contexts.py covers form (b), the ctx's own stream
+    ordered with events."""
+    import torch
+    from entropy_coding_amd import capi
+    return capi.CabacHip(device, stream=torch.cuda.current_stream().cuda_stream)
+
+
 # ------------------------------------------------------------------ generators
 def random_ops(rng, n, ctx_frac=0.6, p_one=None, with_helpers=True, with_align=False, end_trm=True):
     """Random operation stream exercising every BinEncIf entry point and binarisation helper."""

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_assemble_split_count_roundtrip():
     import torch
-    hip = capi.CabacHip(0)
+    hip = H.gpu_ctx()
     orc = H.load_oracle()
     orc.lib.orc_count_emulations.argtypes = [H.u8p, ctypes.c_long]
     rng = np.random.default_rng(12)
@@ -61,7 +61,7 @@ def test_count_emulations_on_crafted_zero_runs():
     """Zero runs of every length and alignment (the kernel takes 64 bytes per step and carries the run length across
     steps), bytes 0..4 mixed in: against the oracle's countStartCodeEmulations (pinned to the reference)."""
     import torch
-    hip = capi.CabacHip(0)
+    hip = H.gpu_ctx()
     orc = H.load_oracle()
     orc.lib.orc_count_emulations.argtypes = [H.u8p, ctypes.c_long]
     rng = np.random.default_rng(5)

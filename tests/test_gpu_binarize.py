@@ -63,7 +63,7 @@ def binarize(hip, se_list):
 
 @pytest.fixture(scope="module")
 def hip():
-    c = capi.CabacHip(0)
+    c = H.gpu_ctx()
     yield c
     c.close()
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hip():
-    return capi.CabacHip(0)
+    return H.gpu_ctx()
 
 
 def _batch(rng, lens, ctx_fracs, with_align=True):

@@ -138,3 +138,32 @@ def test_host_memory_api():
     assert L.cabac_hip_host_unregister(capi.vp(plain.ctypes.data)) == -2
     assert not capi.host_is_pinned(plain)
     a.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_early_error_return_leaves_the_pipeline_idle(pinned):
+    """cabac_hip_encode_batch_payload with two chunks and a payload that only holds the first: the call returns
+    CABAC_HIP_ERR_INVALID from the middle of the pipeline.  Nothing of it may still be in flight or waiting in the bounce
+    ring afterwards: the payload buffer is released at once, and the next call on the same ctx is an ordinary one."""
+    os.environ["CABAC_HIP_CHUNKS"] = "2"
+    try:
+        hip = capi.CabacHip(0)
+        rng = np.random.default_rng(77)
+        desc, records, total = _ragged_batch(rng, 3000, 2500)
+        out_o, res_o = H.load_oracle().encode_batch(desc, records, total)
+        nbytes = np.minimum((res_o["n_bits"].astype(np.int64) + 7) // 8, desc["byte_capacity"].astype(np.int64))
+        small = int(nbytes.sum()) * 2 // 3              # the first chunk (half of the records) fits, the second does not
+        pay = capi.PinnedArray((small,), np.uint8) if pinned else None
+        payload = pay.array if pinned else np.zeros(small, np.uint8)
+        with pytest.raises(capi.CabacHipError) as e:
+            hip.encode_batch_payload(desc, records, payload)
+        assert e.value.status == -2 and "payload_capacity" in str(e.value)
+        if pay is not None:
+            pay.close()                                 # freed right after the failed call
+        del payload
+        junk = [np.full(small, 0xEE, np.uint8) for _ in range(4)]   # the heap block of the pageable payload is reused
+        _check_against_oracle(hip, desc, records, total, pinned)
+        assert all((j == 0xEE).all() for j in junk)    # no stale bounce block was copied into the old payload's memory
+        hip.close()
+    finally:
+        del os.environ["CABAC_HIP_CHUNKS"]

@@ -24,7 +24,7 @@ LEGACY_VARIANTS = {"v1": 1, "v2_L4": 2 | (4 << 8)}
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
 def hip(request):
-    c = capi.CabacHip(0)   # raises without a GPU: there is no fallback
+    c = H.gpu_ctx()   # raises without a GPU: there is no fallback
     c.set_variant(VARIANTS[request.param], VARIANTS[request.param])
     c.variant_name = request.param
     yield c
@@ -310,7 +310,7 @@ def test_legacy_variants_still_bit_exact():
     desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), rng.integers(0, 3, size=len(lens)),
                               H.SUB_FINISH | H.SUB_ALIGN_RBSP)
     for name, v in LEGACY_VARIANTS.items():
-        c = capi.CabacHip(0)
+        c = H.gpu_ctx()
         c.set_variant(v, v)
         out, res = _compare_encode(c, orc, desc, records, total)
         dd = desc.copy(); dd["byte_capacity"] = (res["n_bits"] + 7) // 8

@@ -14,7 +14,7 @@ SHAPES = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32,
 
 @pytest.fixture(scope="module")
 def hip():
-    c = capi.CabacHip(0)
+    c = H.gpu_ctx()
     yield c
     c.close()
 

@@ -57,3 +57,95 @@ def test_encode_beside_decode_on_two_streams(n_sub, top):
     assert np.array_equal(bins.cpu().numpy(), (records >> 15).astype(np.uint8))
     h_enc.close()
     h_dec.close()
+
+
+def test_own_stream_ordered_with_events():
+    """cabac_hip.h, stream ordering contract, form (b): the ctx keeps its own (non-blocking) stream; the producer's fills are
+    ordered in front of the launch with cabac_hip_wait_event and the consumer's reads behind it with cabac_hip_record_event —
+    no host synchronisation anywhere between the fill and the read."""
+    import torch
+    orc = H.load_oracle()
+    rng = np.random.default_rng(99)
+    desc, records, total = _batch(rng, 1500, 2500)
+    want_bytes, want_res = orc.encode_batch(desc, records, total)
+    hip = capi.CabacHip(0)                       # its own stream
+    t_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).cuda()
+    t_rec = torch.from_numpy(records.view(np.int16).copy()).cuda()
+    filled, coded = torch.cuda.Event(), torch.cuda.Event()
+    coded.record()                               # creates the HIP event; re-recorded on the ctx's stream below
+    for _ in range(3):
+        big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        big.fill_(0xA5)                          # a long fill in front of the buffers' own, on torch's stream
+        out = torch.full((total,), 0x5A, dtype=torch.uint8, device="cuda")
+        res = torch.zeros(2 * len(desc), dtype=torch.int32, device="cuda")
+        filled.record()
+        hip.wait_event(filled.cuda_event)
+        hip.encode_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), out.data_ptr(), res.data_ptr())
+        hip.record_event(coded.cuda_event)
+        torch.cuda.current_stream().wait_event(coded)
+        got = res.cpu().numpy().view(H.RESULT_DTYPE)
+        host = out.cpu().numpy()
+        assert np.array_equal(got["n_bits"], want_res["n_bits"]) and not got["flags"].any()
+        for s in range(0, len(desc), 3):
+            o, nb = int(desc["byte_offset"][s]), (int(want_res["n_bits"][s]) + 7) // 8
+            assert np.array_equal(host[o:o + nb], want_bytes[o:o + nb]), s
+        del big
+    hip.close()
+
+
+def test_context_lifetime_in_a_fresh_process_exits_normally():
+    """A child interpreter creates contexts, uses the device path and the host path (so that the copy / kernel streams and the
+    pinned bounce rings exist), closes one context, leaves the other and a pinned array to capi.close_all(), and ends through
+    the interpreter's and the libraries' ordinary teardown: exit status 0, nothing on stderr from the runtime."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import helpers as H
+from entropy_coding_amd import capi
+rng = np.random.default_rng(5)
+recs = [H.random_records(rng, int(n)) for n in rng.integers(1, 4000, size=2500)]
+desc, total = H.make_desc([len(r) for r in recs], rng.integers(0, 64, size=len(recs)), rng.integers(0, 3, size=len(recs)),
+                          H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+records = np.concatenate(recs)
+want, wres = H.load_oracle().encode_batch(desc, records, total)
+a, b = capi.CabacHip(0), H.gpu_ctx()
+pin = capi.PinnedArray(records.shape, np.uint16); pin.array[:] = records
+for hip, src in ((a, records), (b, pin.array)):
+    out, res = hip.encode_batch(desc, src, total)
+    assert np.array_equal(res["n_bits"], wres["n_bits"])
+    dd = desc.copy(); dd["byte_capacity"] = (res["n_bits"] + 7) // 8
+    bins, rd = hip.decode_batch(dd, src, out)
+    assert np.array_equal(bins, (records >> 15).astype(np.uint8))
+a.close()
+capi.close_all()
+assert not capi._live
+print("OK")
+''' % {"tests": H.ROOT + "/tests", "root": H.ROOT}
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "Abort" not in r.stderr and "HSA_STATUS" not in r.stderr, r.stderr[-4000:]
+
+
+def test_context_left_open_at_exit_does_not_abort():
+    """... and a caller that forgets close(): the context, its streams and a pinned array are still alive when the interpreter
+    finalizes (capi's __del__ does not release into a runtime that may be unloading).  The process must still end with status 0."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import helpers as H
+from entropy_coding_amd import capi
+rng = np.random.default_rng(6)
+recs = [H.random_records(rng, 500) for _ in range(64)]
+desc, total = H.make_desc([len(r) for r in recs], [30] * 64, [2] * 64, H.SUB_FINISH)
+hip = capi.CabacHip(0)
+keep = capi.PinnedArray((1 << 20,), np.uint8)
+out, res = hip.encode_batch(desc, np.concatenate(recs), total)
+assert not res["flags"].any()
+print("OK")
+''' % {"tests": H.ROOT + "/tests", "root": H.ROOT}
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -19,17 +19,21 @@ ip = ctypes.POINTER(ctypes.c_int)
 
 @pytest.fixture(scope="module")
 def drv():
-    from entropy_coding_amd import capi
-    capi.load_library()          # builds libcabac_hip.so if stale (and loads torch's HIP runtime first)
-    so = os.path.join(CSRC, "libhost_shim_driver.so")
-    src = os.path.join(CSRC, "host_shim_driver.cpp")
-    lib = os.path.join(H.ROOT, "entropy_coding_amd", "libcabac_hip.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(lib)):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(H.ROOT, "include"),
-                               "-I" + os.path.join(H.ROOT, "entropy_coding_amd", "host"), src,
-                               "-L" + os.path.dirname(lib), "-lcabac_hip", "-Wl,-rpath," + os.path.dirname(lib),
-                               "-o", so])
-    L = ctypes.CDLL(so)
+    san = os.environ.get("CABAC_TEST_SANITIZED_SHIM")   # tests/test_sanitizers.py: shim + driver + oracle-backed stub under ASan
+    if san:
+        L = ctypes.CDLL(san)
+    else:
+        from entropy_coding_amd import capi
+        capi.load_library()          # builds libcabac_hip.so if stale (and loads torch's HIP runtime first)
+        so = os.path.join(CSRC, "libhost_shim_driver.so")
+        src = os.path.join(CSRC, "host_shim_driver.cpp")
+        lib = os.path.join(H.ROOT, "entropy_coding_amd", "libcabac_hip.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(H.ROOT, "include"),
+                                   "-I" + os.path.join(H.ROOT, "entropy_coding_amd", "host"), src,
+                                   "-L" + os.path.dirname(lib), "-lcabac_hip", "-Wl,-rpath,$ORIGIN/../../entropy_coding_amd",
+                                   "-o", so])
+        L = ctypes.CDLL(so)
     L.shim_last_error.restype = ctypes.c_char_p
     L.shim_record_ops.restype = ctypes.c_long
     L.shim_record_ops.argtypes = [u32p, ctypes.c_long, u16p, ctypes.c_long, u32p]
@@ -205,6 +209,68 @@ def test_input_bitstream_mirror(drv):
         if ref is not None:
             rgot, rsub = _run_input_script(ref, data, script)
             assert list(rgot[:n]) == want and (want[-1] == 0xFFFFFFFF or rsub == want_sub), (trial, script)
+
+
+def test_input_bitstream_state_after_a_failed_read(drv):
+    """A read that ends exactly on the last byte succeeds; a read past the end throws "Exceeded FIFO size" (readByte: "FIFO
+    exceeded") and leaves the byte position and the held bits where they were — only the bit counter has moved
+    (bit_stream.cpp:205-208, :240-242).  The scripts carry on after the throw (op 10) and probe the state (ops 7 / 8 / 9 / 5 /
+    4); the mirror and, where it is built, the reference's own class must answer alike."""
+    ref = None
+    if H.ref_available():
+        ref = H.load_ref().lib.ref_input_bitstream_script
+        ref.restype = ctypes.c_long
+        ref.argtypes = drv.shim_input_bitstream_script.argtypes
+    probe = [(7, 0), (8, 0), (9, 0), (5, 0), (4, 0)]
+    rng = np.random.default_rng(23)
+    cases = []
+    data4 = np.array([0xA5, 0x3C, 0x81, 0x7E], np.uint8)
+    cases.append((data4, [(10, 0), (0, 24), (0, 8)] + probe))                         # ends exactly on the last byte
+    cases.append((data4, [(10, 0), (0, 24), (0, 9)] + probe + [(0, 8)] + probe))       # one bit too many, then what is there
+    cases.append((data4, [(10, 0), (0, 3), (0, 32)] + probe + [(0, 29)] + probe))      # held bits + 4 bytes > what is left
+    cases.append((data4, [(10, 0), (0, 32), (1, 0)] + probe + [(0, 1)] + probe))       # readByte / read at the very end
+    cases.append((data4, [(10, 0), (0, 5), (2, 40)] + probe))                          # extractSubstream running dry
+    for _ in range(60):
+        data = rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)
+        script = [(10, 0)]
+        for _ in range(int(rng.integers(2, 10))):
+            script.append((0, int(rng.integers(0, 33))))
+            if rng.random() < 0.5:
+                script += probe
+        cases.append((data, script + probe))
+    for data, script in cases:
+        got, _ = _run_input_script(drv.shim_input_bitstream_script, data, script)
+        # model: bit position, with a failed read leaving it alone but counting its bits
+        pos, nread, want = 0, 0, []
+        bits = "".join(format(int(b), "08b") for b in data)
+        for op, arg in script:
+            if op == 0:
+                nread += arg
+                if -(-(pos + arg) // 8) > len(data):
+                    want.append(0xFFFFFFFF)
+                else:
+                    want.append(int(bits[pos:pos + arg], 2) if arg else 0)
+                    pos += arg
+            elif op == 7:
+                want.append(-(-pos // 8))
+            elif op == 8:
+                want.append(nread)
+            elif op == 5:
+                want.append(-pos % 8)
+            elif op == 4:
+                want.append(8 * len(data) - pos)
+            else:
+                want.append(None)                       # compared with the reference only
+        if all(op != 2 for op, _ in script):            # (the model above does not follow extractSubstream)
+            for g, w in zip(got, want):
+                assert w is None or int(g) == w, (data.tolist(), script, list(got), want)
+        if ref is not None:
+            rgot, _ = _run_input_script(ref, data, script)
+            # the held byte itself (op 9) is only defined while some of its bits are unread
+            for i, (op, _) in enumerate(script):
+                if op == 9 and got[i + 1] == 0 == rgot[i + 1]:
+                    continue
+                assert got[i] == rgot[i], (data.tolist(), script, list(got), list(rgot))
 
 
 # ------------------------------------------------------------------ GPU

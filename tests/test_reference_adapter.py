@@ -12,14 +12,16 @@ import pytest
 
 import helpers as H
 
-SO = os.path.join(H.ORACLE_DIR, "_ref", "libadapter_test.so")
+SAN = os.environ.get("CABAC_TEST_SANITIZED_ADAPTER")   # tests/test_sanitizers.py: everything in one library under ASan + UBSan
+SO = SAN or os.path.join(H.ORACLE_DIR, "_ref", "libadapter_test.so")
 pytestmark = pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libadapter_test.so not built")
 
 
 @pytest.fixture(scope="module")
 def adp():
-    from entropy_coding_amd import capi
-    capi.load_library()
+    if not SAN:
+        from entropy_coding_amd import capi
+        capi.load_library()
     cwd = os.getcwd()
     os.chdir(tempfile.mkdtemp(prefix="cabac_ref_"))   # reference log.cpp:3-4 creates bin_log.txt/bit_log.txt in CWD
     try:
