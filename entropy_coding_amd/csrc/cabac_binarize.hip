@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "cabac_hip.h"
+#include "cabac_rem_abs.hpp"
 #include "cabac_kernels.h"
 
 namespace cabac {
@@ -43,31 +44,12 @@ __device__ __forceinline__ SeCode se_decode(uint32_t w0, uint32_t value) {
     s.code1 = value;
     s.n = s.len1;
     break;
-  case CABAC_SE_REM_ABS: {  // arith_codec.cpp:426-458
-    const uint32_t rice = (w0 >> 4) & 31u, cutoff = (w0 >> 9) & 31u, max_log2 = (w0 >> 14) & 63u;
-    const uint32_t threshold = cutoff << rice;
-    if (value < threshold) {
-      const uint32_t length = (value >> rice) + 1;
-      s.code1 = (1u << length) - 2u;
-      s.len1 = length;
-      s.code2 = value & ((1u << rice) - 1u);
-      s.len2 = rice;
-    } else {
-      const uint32_t max_prefix = 32u - cutoff - max_log2;
-      uint32_t prefix_len = 0, suffix_len;
-      const uint32_t code = (value >> rice) - cutoff;
-      if (code >= ((1u << max_prefix) - 1u)) {
-        prefix_len = max_prefix;
-        suffix_len = max_log2;
-      } else {
-        while (code > ((2u << prefix_len) - 2u)) prefix_len++;
-        suffix_len = prefix_len + rice + 1;
-      }
-      s.len1 = prefix_len + cutoff;
-      s.code1 = (1u << s.len1) - 1u;
-      s.code2 = ((code - ((1u << prefix_len) - 1u)) << rice) | (value & ((1u << rice) - 1u));
-      s.len2 = suffix_len;
-    }
+  case CABAC_SE_REM_ABS: {  // arith_codec.cpp:426-458 (the code word: host/cabac_rem_abs.hpp)
+    const cabac_code::RemAbsCode c = cabac_code::rem_abs_code(value, (w0 >> 4) & 31u, (w0 >> 9) & 31u, (w0 >> 14) & 63u);
+    s.len1 = c.ones + c.stop;                    // the run and its separator as one field: ones, then a 0
+    s.code1 = ((1u << c.ones) - 1u) << c.stop;   // (ones + stop <= 32: 1u << 32 does not occur, the longest run is 32 - maxLog2)
+    s.len2 = c.tail_bits;
+    s.code2 = c.tail;
     s.n = s.len1 + s.len2;
     break;
   }

@@ -21,8 +21,6 @@ hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const caba
 // v4 "quad" kernels (cabac_kernels_v4.hip): four substreams per wave
 hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results);
-hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,

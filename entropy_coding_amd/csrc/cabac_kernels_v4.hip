@@ -366,7 +366,11 @@ __device__ __forceinline__ QuadEncInfo quad_unpack(uint32_t info) {
 }
 
 // finish(), arith_codec.cpp:339-357, on the exact code value (+ writeByteAlignment, bit_stream.cpp:152-155)
-__device__ __forceinline__ uint32_t quad_enc_finish(QuadEnc &e, bool align_rbsp, bool writer) {
+// probe (CABAC_SUB_PROBE): no flush; the answer of getNumWrittenBits() (arith_codec.cpp:482-485) instead — every shift so far
+// has either left as a stored unit (8 * pos), waits as the buffered unit or an outstanding 0xFFFF (16 * nbuf), or is
+// still inside low (pend)
+__device__ __forceinline__ uint32_t quad_enc_finish(QuadEnc &e, bool align_rbsp, bool writer, bool probe = false) {
+  if (probe) return 8u * e.pos + 16u * (uint32_t)e.nbuf + (uint32_t)e.pend;
   const uint32_t total = (uint32_t)(9 + e.pend);
   if ((e.low >> total) & 1ull) {
     quad_put16(e, e.buf + 1u, writer);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(64) void encode_kernel_v4(uint32_t n_sub, const cab
     else quad_enc_steps<true, false>(f, e, writer, QuadPost());
   }
 
-  const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+  const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer, (d.init_id & CABAC_SUB_PROBE) != 0) : 0u;
   const uint64_t bad_mask = __ballot(bad != 0);  // row-wide OR of the bad-record flag
   const bool row_bad = ((bad_mask >> (row * 16u)) & 0xffffull) != 0;
   if (writer) {
@@ -573,152 +577,8 @@ __device__ unsigned long long g_v5_prof[16];
 #define V5_ADD(slot, t0, t1)
 #endif
 
-template <int U>
-__global__ __launch_bounds__(192 * U) void encode_kernel_v5(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
-                                                            const uint16_t *__restrict__ records,
-                                                            uint8_t *__restrict__ bytes,
-                                                            cabac_substream_result *__restrict__ results) {
-  __shared__ uint32_t ctx_all[U * kQuadSubs * kQuadCtxStride];
-  __shared__ uint32_t mail_all[U][2][64];
-  __shared__ uint32_t post_lo[U][2][4 * kQuadSubs], post_hi[U][2][4 * kQuadSubs], post_pend[U][2][4 * kQuadSubs];
-  __shared__ uint32_t fin_lo[U][kQuadSubs], fin_hi[U][kQuadSubs], fin_pend[U][kQuadSubs];
-  __shared__ uint32_t unit_list[U][kQuadSubs][kUnitSlots];
-  __shared__ uint32_t bad_rows[U];
-  __shared__ uint32_t wg_max_n;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
-  const uint32_t unit = wave % U, role = wave / U;  // role 0: context wave, 1: chain wave, 2: output wave
-  const uint32_t sub = (blockIdx.x * U + unit) * kQuadSubs + row;
-  const bool live = sub < n_sub;
-  const cabac_substream_desc d = desc[live ? sub : 0];
-  const uint32_t n = live ? d.n_records : 0u;
-  uint32_t (*mail)[64] = mail_all[unit];
-
-  if (threadIdx.x == 0) wg_max_n = 0;
-  __syncthreads();
-  atomicMax(&wg_max_n, n);
-  __syncthreads();
-  const uint32_t max_n = wg_max_n;
-
-  if (role == 0) {
-    // ---- context wave: the fields of step base + 16 while the chain wave codes step base ----------
-    const uint16_t *rec = records + d.rec_offset;
-    uint32_t *rctx = ctx_all + (unit * kQuadSubs + row) * kQuadCtxStride;
-    quad_ctx_init(rctx, d.qp, d.init_id & 3u, j);
-    uint32_t bad = 0;
-    // record loads without lane conditions (an exec region per step costs a scalar wait on a vector compare):
-    // past the end of a row they read a valid address and phase (a) ignores the value
-    const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
-    const uint32_t last_rec = n != 0 ? n - 1u : 0u;
-    const uint32_t cur_rec = rec_safe[min(j, last_rec)];
-    uint32_t next_rec = rec_safe[min(16u + j, last_rec)];
-    mail[0][lane] = quad_phase_a(cur_rec, j < n, lane, row, rctx, bad);  // step 0
-    __syncthreads();
-    uint32_t slot = 1;
-    for (uint32_t base = 0; base < max_n; base += 16) {
-      const uint32_t r = next_rec;
-      next_rec = rec_safe[min(base + 32u + j, last_rec)];
-      V5_TICK(t2);
-      const uint32_t info = quad_phase_a(r, base + 16u + j < n, lane, row, rctx, bad);
-      mail[slot][lane] = info;
-      slot ^= 1u;
-      V5_TICK(t3);
-      __syncthreads();
-      V5_TICK(t4);
-      V5_ADD(2, t2, t3);  // phase (a)
-      V5_ADD(3, t3, t4);  // waiting at the barrier
-    }
-    const uint64_t bad_mask = __ballot(bad != 0);
-    if (lane == 0) {
-      uint32_t rows = 0;
-      for (uint32_t k = 0; k < 4; k++) rows |= ((bad_mask >> (16u * k)) & 0xffffull) ? (1u << k) : 0u;
-      bad_rows[unit] = rows;
-    }
-    __syncthreads();
-  } else if (role == 1) {
-    // ---- chain wave --------------------------------------------------------------------------
-    // its instruction stream is the longest: let it win issue arbitration against the two waves it shares
-    // its SIMD with
-    __builtin_amdgcn_s_setprio(3);
-    QuadEnc e;
-    e.low = 0;
-    e.range = 510;  // start(), arith_codec.cpp:329-337
-    e.pend = 0;
-    const bool poster = j == 0;
-    __syncthreads();
-    uint32_t slot = 0;
-    for (uint32_t base = 0; base < max_n; base += 16) {
-      const uint32_t info = mail[slot][lane];
-      QuadPost post;
-      post.lo = &post_lo[unit][slot][row];
-      post.hi = &post_hi[unit][slot][row];
-      post.pend = &post_pend[unit][slot][row];
-      slot ^= 1u;
-      const QuadEncInfo f = quad_unpack(info);
-      V5_TICK(t0);
-      if (__ballot(info >> 12) == 0) quad_enc_steps<false, true>(f, e, poster, post);
-      else quad_enc_steps<true, true>(f, e, poster, post);
-      V5_TICK(t1);
-      __syncthreads();
-      V5_TICK(t2);
-      V5_ADD(4, t0, t1);  // chain
-      V5_ADD(5, t1, t2);  // waiting at the barrier
-    }
-    if (poster) {
-      fin_lo[unit][row] = (uint32_t)e.low;
-      fin_hi[unit][row] = (uint32_t)(e.low >> 32);
-      fin_pend[unit][row] = (uint32_t)e.pend;
-    }
-    __syncthreads();
-  } else {
-    // ---- output wave: while the chain wave codes step base, write out the units listed one iteration ago
-    // (posted during step base - 32) and list what was posted during step base - 16 ----------------------
-    QuadEnc e;  // output state; low / pend are loaded from the chain wave's posts
-    e.low = 0;
-    e.range = 0;
-    e.pend = 0;
-    e.buf = 0;
-    e.nbuf = 0;
-    e.pos = 0;
-    e.dst = bytes + d.byte_offset;
-    e.cap = live ? d.byte_capacity : 0u;
-    const bool writer = live && j == 0;
-    uint32_t *list = unit_list[unit][row];
-    __syncthreads();
-    uint32_t slot = 1;
-    QuadUnits units;
-    units.m = 0;
-    units.odd_rows = 0;
-    units.store_lanes = 0;
-    bool listed = false;
-    for (uint32_t base = 0; base < max_n; base += 16) {
-      V5_TICK(t0);
-      if (listed) quad_emit_units(e, units, j, list, writer);
-      V5_TICK(t1);
-      listed = base != 0;
-      if (listed) units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
-      slot ^= 1u;
-      V5_TICK(t2);
-      __syncthreads();
-      V5_ADD(0, t0, t1);  // emit
-      V5_ADD(1, t1, t2);  // list
-    }
-    __syncthreads();  // the chain wave has posted its last step and what it still holds; bad_rows is written
-    if (listed) quad_emit_units(e, units, j, list, writer);
-    if (max_n != 0) {
-      units = quad_list_units(e, post_lo[unit][slot], post_hi[unit][slot], post_pend[unit][slot], row, j, live, list);
-      quad_emit_units(e, units, j, list, writer);
-    }
-    e.low = ((uint64_t)fin_hi[unit][row] << 32) | fin_lo[unit][row];
-    e.pend = (int32_t)fin_pend[unit][row];
-    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
-    if (writer) {
-      cabac_substream_result res;
-      res.n_bits = n_bits;
-      res.flags = (e.pos > e.cap ? CABAC_RES_OVERFLOW : 0u) | (((bad_rows[unit] >> row) & 1u) ? CABAC_RES_BAD_RECORD : 0u);
-      results[sub] = res;
-    }
-  }
-}
+// (encode_kernel_v5, the three-wave encoder described above, was retired in round 3: v6 and v7 below grew out of it and it
+// was never dispatched after them; its pieces that they share — QuadPost, quad_list_units, quad_emit_units — stay.)
 
 // ---------------------------------------------------------------------------------------------
 // v6: the three-wave encoder with `low` taken out of the chain wave.
@@ -1124,7 +984,7 @@ __global__ __launch_bounds__(256 * U) void encode_kernel_v6(uint32_t n_sub, cons
     __syncthreads();
     e.low = fin_acc[unit][row];
     e.pend = (int32_t)fin_rem[unit][row];
-    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer, (d.init_id & CABAC_SUB_PROBE) != 0) : 0u;
     if (writer) {
       cabac_substream_result res;
       res.n_bits = n_bits;
@@ -1413,7 +1273,7 @@ __global__ __launch_bounds__(64 * (U + 2 + (U + 1) / 2)) void encode_kernel_v7(u
     }
     e.low = ((uint64_t)fin_hi[local] << 32) | fin_lo[local];
     e.pend = (int32_t)fin_pend[local];
-    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer) : 0u;
+    const uint32_t n_bits = live ? quad_enc_finish(e, (d.init_id & CABAC_SUB_ALIGN_RBSP) != 0, writer, (d.init_id & CABAC_SUB_PROBE) != 0) : 0u;
     if (writer) {
       cabac_substream_result res;
       res.n_bits = n_bits;
@@ -1953,29 +1813,6 @@ hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
                             uint8_t *bytes, cabac_substream_result *results) {
   hipLaunchKernelGGL(encode_kernel_v4, dim3((n_sub + kQuadSubs - 1) / kQuadSubs), dim3(64), 0, st, n_sub, desc, records,
                      bytes, results);
-  return hipGetLastError();
-}
-
-hipError_t launch_encode_v5(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight) {
-  const uint32_t units = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  const uint32_t units_on_chip = (max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs;
-  // Units (wave triples) per workgroup (CABAC_V5_UNITS overrides for experiments).  Four: the twelve waves of a
-  // workgroup are dealt to the CU's four SIMDs in order, so that every SIMD gets one wave of each kind whatever ran
-  // before.  Single-pair workgroups are a little faster when the dispatcher happens to spread them well (1.16
-  // against 1.20 ms on C4) but took 1.55 ms when the previous launch had another geometry, and 2.7 against 2.0 ms
-  // with 8 192 substreams.  (Replacing the barrier by per-pair LDS counters, so that the four pairs do not wait
-  // for each other, was tried and is slower: the polling wave takes issue slots from its partner.)
-  static int forced = -1;
-  if (forced < 0) {
-    const char *e = getenv("CABAC_V5_UNITS");
-    forced = e ? atoi(e) : 0;
-  }
-  // fewer pairs than SIMD quads (256 CUs x 4 pairs): single-pair workgroups, so that they spread over all CUs
-  const int upw = forced ? forced : (units_on_chip >= 1024u ? 4 : 1);
-  if (upw == 4) hipLaunchKernelGGL(encode_kernel_v5<4>, dim3((units + 3) / 4), dim3(768), 0, st, n_sub, desc, records, bytes, results);
-  else if (upw == 2) hipLaunchKernelGGL(encode_kernel_v5<2>, dim3((units + 1) / 2), dim3(384), 0, st, n_sub, desc, records, bytes, results);
-  else hipLaunchKernelGGL(encode_kernel_v5<1>, dim3(units), dim3(192), 0, st, n_sub, desc, records, bytes, results);
   return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // Host-side mirror of the reference's bin-codec interface — see cabac_hip_host.hpp.
 #include "cabac_hip_host.hpp"
+#include "cabac_rem_abs.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -237,6 +238,20 @@ void HipBatch::flush() {
   }
 }
 
+uint32_t HipBatch::numWrittenBits(const uint16_t *records, size_t n_records, int qp, int initId) {
+  cabac_substream_desc d{};
+  d.n_records = uint32_t(n_records);
+  d.qp = qp;
+  d.init_id = uint32_t(initId) | CABAC_SUB_PROBE;
+  d.byte_capacity = uint32_t(cabac_hip_encode_bound(n_records, n_records, n_records));  // any record kind, worst case
+  std::vector<uint8_t> scratch(d.byte_capacity + 1u);
+  const uint16_t none = 0;
+  cabac_substream_result res{};
+  const int rc = cabac_hip_encode_batch(handle(), 1, &d, n_records ? records : &none, n_records, scratch.data(), d.byte_capacity, &res);
+  check_status(m_ctx, rc, "cabac_hip_encode_batch (probe)");
+  return res.n_bits;
+}
+
 std::vector<uint64_t> HipBatch::estimate(const std::vector<EstimateJob> &jobs) {
   const uint32_t n = uint32_t(jobs.size());
   std::vector<uint64_t> cost(n, 0);
@@ -457,25 +472,9 @@ void BitEstimatorHip::encodeBinsEP(unsigned, unsigned numBins) {  // arith_codec
 }
 
 void BitEstimatorHip::encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) {
-  // arith_codec.cpp:653-677: the length of the code word in bits
-  const unsigned threshold = cutoff << goRicePar;
-  unsigned nbits;
-  if (bins < threshold) {
-    nbits = (bins >> goRicePar) + 1 + goRicePar;
-  } else {
-    const unsigned maxPrefixLength = 32 - cutoff - unsigned(maxLog2TrDynamicRange);
-    unsigned prefixLength = 0, suffixLength;
-    const unsigned codeValue = (bins >> goRicePar) - cutoff;
-    if (codeValue >= ((1u << maxPrefixLength) - 1)) {
-      prefixLength = maxPrefixLength;
-      suffixLength = unsigned(maxLog2TrDynamicRange);
-    } else {
-      while (codeValue > ((2u << prefixLength) - 2u)) prefixLength++;
-      suffixLength = prefixLength + goRicePar + 1;
-    }
-    nbits = cutoff + prefixLength + suffixLength;
-  }
-  for (unsigned i = 0; i < nbits; i++) put(CABAC_REC_EP);
+  // one bit per bypass bin of the code word (arith_codec.cpp:653-677)
+  const unsigned n = cabac_code::rem_abs_code(bins, goRicePar, cutoff, unsigned(maxLog2TrDynamicRange)).length();
+  for (unsigned i = 0; i < n; i++) put(CABAC_REC_EP);
 }
 
 void BinEncoderHip::encodeBin(unsigned bin, unsigned ctxId) {
@@ -498,31 +497,18 @@ void BinEncoderHip::encodeBinsEP(unsigned bins, unsigned numBins) {
 }
 
 void BinEncoderHip::encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) {
-  // arith_codec.cpp:426-458
-  const unsigned threshold = cutoff << goRicePar;
-  if (bins < threshold) {
-    const unsigned bitMask = (1u << goRicePar) - 1;
-    const unsigned length = (bins >> goRicePar) + 1;
-    encodeBinsEP((1u << length) - 2, length);
-    encodeBinsEP(bins & bitMask, goRicePar);
-  } else {
-    const unsigned maxPrefixLength = 32 - cutoff - unsigned(maxLog2TrDynamicRange);
-    unsigned prefixLength = 0, suffixLength;
-    unsigned codeValue = (bins >> goRicePar) - cutoff;
-    if (codeValue >= ((1u << maxPrefixLength) - 1)) {
-      prefixLength = maxPrefixLength;
-      suffixLength = unsigned(maxLog2TrDynamicRange);
-    } else {
-      while (codeValue > ((2u << prefixLength) - 2u)) prefixLength++;
-      suffixLength = prefixLength + goRicePar + 1;
-    }
-    const unsigned totalPrefixLength = prefixLength + cutoff;
-    const unsigned bitMask = (1u << goRicePar) - 1;
-    const unsigned prefix = (1u << totalPrefixLength) - 1;
-    const unsigned suffix = ((codeValue - ((1u << prefixLength) - 1)) << goRicePar) | (bins & bitMask);
-    encodeBinsEP(prefix, totalPrefixLength);
-    encodeBinsEP(suffix, suffixLength);
-  }
+  // arith_codec.cpp:426-458: the code word's bypass bins as records, in order
+  const cabac_code::RemAbsCode c = cabac_code::rem_abs_code(bins, goRicePar, cutoff, unsigned(maxLog2TrDynamicRange));
+  BinCounter::addEP(c.length());
+  for (uint32_t i = 0; i < c.ones; i++) put(CABAC_REC_EP, 1);
+  if (c.stop) put(CABAC_REC_EP, 0);
+  for (uint32_t i = c.tail_bits; i-- > 0;) put(CABAC_REC_EP, (c.tail >> i) & 1u);
+}
+
+unsigned BinEncoderHip::getNumWrittenBits() {
+  if (m_mode != Immediate) fail("getNumWrittenBits: nothing is coded before HipBatch::flush() in Deferred mode");
+  if (!m_Bitstream) fail("getNumWrittenBits: no bitstream (init not called)");
+  return m_Bitstream->getNumberOfWrittenBits() + m_batch.numWrittenBits(m_records.data(), m_records.size(), m_qp, m_initId);
 }
 
 void BinEncoderHip::encodeBinTrm(unsigned bin) {
@@ -650,23 +636,8 @@ unsigned BinDecoderHip::decodeRemAbsEP(unsigned goRicePar, unsigned cutoff, int 
 }
 
 void BinDecoderHip::planRemAbsEP(unsigned value, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) {
-  // the number of bypass bins encodeRemAbsEP(value, ...) codes (arith_codec.cpp:426-458): a planner that knows the
-  // value (a replay of recorded syntax) reserves exactly those
-  const unsigned threshold = cutoff << goRicePar;
-  if (value < threshold) {
-    planBinEP((value >> goRicePar) + 1u + goRicePar);
-    return;
-  }
-  const unsigned maxPrefix = 32u - cutoff - unsigned(maxLog2TrDynamicRange);
-  unsigned prefix = 0, code = (value >> goRicePar) - cutoff, suffix;
-  if (code >= ((1u << maxPrefix) - 1u)) {
-    prefix = maxPrefix;
-    suffix = unsigned(maxLog2TrDynamicRange);
-  } else {
-    while (code > ((2u << prefix) - 2u)) prefix++;
-    suffix = prefix + goRicePar + 1u;  // +1: the separator bit
-  }
-  planBinEP(cutoff + prefix + suffix);
+  // a planner that knows the value (a replay of recorded syntax) reserves exactly the bypass bins encodeRemAbsEP codes
+  planBinEP(cabac_code::rem_abs_code(value, goRicePar, cutoff, unsigned(maxLog2TrDynamicRange)).length());
 }
 
 }  // namespace EntropyCodingAMD

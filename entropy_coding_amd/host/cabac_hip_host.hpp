@@ -224,6 +224,11 @@ public:
     OutputBitstream *sink = nullptr;
     std::function<void(const uint8_t *bytes, uint32_t whole, uint32_t tail_bits)> deliver;
   };
+  // BinEncoderBase::getNumWrittenBits() (arith_codec.cpp:482-485) of an encoder that has coded `records` since
+  // reset(qp, initId) and flushed nothing yet: one launch with CABAC_SUB_PROBE (cabac_hip.h).  For the recording encoders'
+  // Immediate mode — the reference asks this mid-substream only in its window-size training helper (cabac_writer.cpp:83-96).
+  uint32_t numWrittenBits(const uint16_t *records, size_t n_records, int qp, int initId);
+
   void submit(Pending &&p) { m_pending.push_back(std::move(p)); }
   const std::vector<Pending> &pendingSubstreams() const { return m_pending; }  // finished, not yet coded (flush() codes them)
 
@@ -296,9 +301,10 @@ public:
   void align() override;
   uint32_t getNumBins() override { return BinCounter::getAll(); }
   bool isEncoding() override { return true; }
-  // Mid-stream arithmetic state lives on the device only; the reference uses this call solely in
-  // the window-size training helper estBits (cabac_writer.cpp:83-96), which is out of scope.
-  unsigned getNumWrittenBits() override { throw Exception("getNumWrittenBits: not available from a recording encoder"); }
+  // arith_codec.cpp:482-485.  The arithmetic state lives on the device: in Immediate mode the bins recorded so far are
+  // coded by one launch that flushes nothing and reports the count (HipBatch::numWrittenBits); in Deferred mode nothing
+  // is coded before flush(), and the call throws.  (The reference asks this only in estBits, cabac_writer.cpp:83-96.)
+  unsigned getNumWrittenBits() override;
 
   const RecordVector &records() const { return m_records; }
 

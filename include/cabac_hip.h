@@ -112,6 +112,12 @@ typedef struct cabac_substream_desc {
 #define CABAC_SUB_ALIGN_RBSP 0x200u /* encode, with FINISH: also OutputBitstream::writeByteAlignment() \
                                        (bit_stream.cpp:152-155): stop bit '1' + zero pad            */
 
+#define CABAC_SUB_PROBE 0x400u /* encode, instead of FINISH: nothing is flushed; results[].n_bits receives what   \
+                                 BinEncoderBase::getNumWrittenBits() (arith_codec.cpp:482-485) would answer after \
+                                 the substream's records — bits in the bitstream + buffered bytes + the bits of   \
+                                 low already shifted out, i.e. the sum of all renormalisation shifts — and the    \
+                                 bytes written are unspecified                                                    */
+
 typedef struct cabac_substream_result {
   uint32_t n_bits; /* encode: bits written (8*whole bytes + held bits, i.e.
                       OutputBitstream::getNumberOfWrittenBits(), bit_stream.cpp:60-62);

@@ -23,6 +23,7 @@
 #include "context_modelling.hpp"  // reference (CUCtx)
 #include "unit_tools.hpp"  // reference (TU::isTSAllowed)
 #include "cabac_hip_host.hpp"
+#include "cabac_rem_abs.hpp"
 
 // the reference's CHECK/THROW name `Exception` unqualified (type_def.hpp:319-326); inside this
 // namespace that would pick EntropyCodingAMD::Exception, so throw the reference's type explicitly
@@ -90,14 +91,12 @@ public:
     for (int i = int(numBins) - 1; i >= 0; i--) put(CABAC_REC_EP, (bins >> i) & 1u);
   }
   void encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned cutoff, int maxLog2TrDynamicRange) override {
-    // the binarisation is this repo's (host/cabac_hip_host.cpp), re-used through a tiny recorder
-    struct Fwd : EntropyCodingAMD::BinEncoderHip {
-      using BinEncoderHip::BinEncoderHip;
-    };
-    Fwd tmp(m_batch);
-    tmp.encodeRemAbsEP(bins, goRicePar, cutoff, maxLog2TrDynamicRange);
-    EntropyCoding::BinCounter::addEP(unsigned(tmp.records().size()));
-    m_records.insert(m_records.end(), tmp.records().begin(), tmp.records().end());
+    // the code word is this repo's statement of it (host/cabac_rem_abs.hpp); its bypass bins as records, in order
+    const cabac_code::RemAbsCode c = cabac_code::rem_abs_code(bins, goRicePar, cutoff, unsigned(maxLog2TrDynamicRange));
+    EntropyCoding::BinCounter::addEP(c.length());
+    for (uint32_t i = 0; i < c.ones; i++) put(CABAC_REC_EP, 1);
+    if (c.stop) put(CABAC_REC_EP, 0);
+    for (uint32_t i = c.tail_bits; i-- > 0;) put(CABAC_REC_EP, (c.tail >> i) & 1u);
   }
   void encodeBinTrm(unsigned bin) override {
     EntropyCoding::BinCounter::addTrm();
@@ -106,9 +105,20 @@ public:
   void align() override { put(CABAC_REC_ALIGN, 0); }
   uint32_t getNumBins() override { return EntropyCoding::BinCounter::getAll(); }
   bool isEncoding() override { return true; }
-  unsigned getNumWrittenBits() override { HIPREF_THROW("getNumWrittenBits: not available from a recording encoder"); }
+  unsigned getNumWrittenBits() override {  // arith_codec.cpp:482-485; Immediate mode: one probing launch (HipBatch::numWrittenBits)
+    HIPREF_CHECK(m_mode != Immediate, "getNumWrittenBits: nothing is coded before HipBatch::flush() in Deferred mode");
+    HIPREF_CHECK(!m_Bitstream, "getNumWrittenBits() without a bitstream");
+    try {
+      return m_Bitstream->getNumberOfWrittenBits() + m_batch.numWrittenBits(m_records.data(), m_records.size(), m_qp, m_initId);
+    } catch (const EntropyCodingAMD::Exception &e) {
+      HIPREF_THROW(e.what());
+    }
+  }
   void setBinStorage(bool) override {}
   const EntropyCoding::BinStore *getBinStore() const override { return nullptr; }
+  // arith_codec.cpp:594-601 hands out a fresh encoder only while the bin store is in use (window-size training); this
+  // encoder keeps no bin store (setBinStorage is a no-op, getBinStore() is null), so there is none to hand out — the
+  // reference's own answer for m_BinStore.inUse() == false
   EntropyCoding::BinEncIf *getTestBinEncoder() const override { return nullptr; }
 
   const EntropyCodingAMD::RecordVector &records() const { return m_records; }

@@ -111,6 +111,36 @@ long adapter_encode(int which, const uint32_t *ops, long n_ops, int qp, int init
   }
 }
 
+// getNumWrittenBits() (arith_codec.cpp:482-485) asked after every `every`-th op, on the reference's BinEncoder_Std (which 0) and
+// on BinEncoderHipRef in Immediate mode (which 1: one probing launch per question); the bitstream already holds `lead_bits`
+// bits, as a substream's does after earlier ones.  Returns the number of answers.
+long adapter_num_written_bits(int which, const uint32_t *ops, long n_ops, int qp, int initId, int every, int lead_bits,
+                              uint32_t *answers, long cap) {
+  try {
+    OutputBitstream bs;
+    if (lead_bits) bs.write((1u << lead_bits) - 1u, lead_bits);
+    EntropyCodingAMD::HipBatch batch(0);
+    BinEncoder_Std std_enc;
+    EntropyCodingAMD::BinEncoderHipRef hip_enc(batch, EntropyCodingAMD::BinEncoderHipRef::Immediate);
+    BinEncIf &e = which == 0 ? static_cast<BinEncIf &>(std_enc) : static_cast<BinEncIf &>(hip_enc);
+    CABACWriter w(e);
+    w.initBitstream(&bs);
+    e.reset(qp, initId);
+    long n = 0;
+    for (long i = 0; i < n_ops; i++) {
+      drive(w, e, ops + 4 * i, 1);
+      if ((i + 1) % every == 0 || i + 1 == n_ops) {
+        if (n >= cap) return -3;
+        answers[n++] = e.getNumWrittenBits();
+      }
+    }
+    return n;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 // CPU only: what the adapter recorded under the reference's CABACWriter
 long adapter_record(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, uint32_t *numBins) {
   try {

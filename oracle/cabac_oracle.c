@@ -362,6 +362,10 @@ static void bz_trunc_bin(bin_enc *e, unsigned symbol, unsigned max_symbol) {
 
 /* ---------------------------------------------------------------- encode drivers */
 static long finish_stream(bin_enc *e, bit_sink *s, int flags, uint32_t *n_bits) {
+  if (flags & 4) { /* probe: BinEncoderBase::getNumWrittenBits, arith_codec.cpp:482-485; nothing is flushed */
+    *n_bits = (uint32_t)(s->n * 8 + s->nheld) + 8u * (uint32_t)e->num_buffered + 23u - (uint32_t)e->bits_left;
+    return 0;
+  }
   if (flags & 1) enc_finish(e);
   if (flags & 2) { /* writeByteAlignment, bit_stream.cpp:152-155 */
     sink_put(s, 1, 1);
@@ -785,7 +789,8 @@ void orc_encode_batch(const void *desc_, uint32_t first, uint32_t count, const u
   const cabac_substream_desc *desc = (const cabac_substream_desc *)desc_;
   for (uint32_t s = first; s < first + count; s++) {
     const cabac_substream_desc *d = &desc[s];
-    int flags = ((d->init_id & CABAC_SUB_FINISH) ? 1 : 0) | ((d->init_id & CABAC_SUB_ALIGN_RBSP) ? 2 : 0);
+    int flags = ((d->init_id & CABAC_SUB_FINISH) ? 1 : 0) | ((d->init_id & CABAC_SUB_ALIGN_RBSP) ? 2 : 0) |
+                ((d->init_id & CABAC_SUB_PROBE) ? 4 : 0);
     uint32_t nbits = 0;
     long rc = orc_encode_records(records + d->rec_offset, d->n_records, d->qp, (int)(d->init_id & 3),
                                  flags, bytes + d->byte_offset, d->byte_capacity, &nbits);

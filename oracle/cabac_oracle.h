@@ -40,7 +40,8 @@ void orc_ctx_init(int qp, int init_id, uint16_t *s0, uint16_t *s1, uint8_t *rate
 void orc_ctx_trace(int qp, int init_id, int ctx_id, const uint8_t *bins, int n, unsigned range,
                    uint8_t *state8, uint8_t *lps, uint16_t *s0_after, uint16_t *s1_after);
 
-/* flags: bit0 finish(), bit1 writeByteAlignment().  Returns bytes written to out (whole bytes
+/* flags: bit0 finish(), bit1 writeByteAlignment(), bit2 probe: nothing is flushed, *n_bits = getNumWrittenBits()
+ * (arith_codec.cpp:482-485) and 0 is returned.  Returns bytes written to out (whole bytes
  * plus one MSB-aligned partial byte if *n_bits % 8), or <0: -2 bad op/record, -3 capacity.
  * n_bins_out (may be NULL): {ctx, EP, TRM} BinCounter totals (arith_codec.cpp:281-316). */
 long orc_encode_ops(const uint32_t *ops, long n_ops, int qp, int init_id, int flags, uint8_t *out,

@@ -211,6 +211,10 @@ long ref_encode_records(const uint16_t *rec, long n, int qp, int initId, int fla
       else if (id == 0x1fd) e.align();
       else { strcpy(g_err, "bad record"); return -2; }
     }
+    if (flags & 4) {  // probe: the reference's own getNumWrittenBits(), nothing flushed
+      *n_bits = e.getNumWrittenBits();
+      return 0;
+    }
     if (flags & 1) e.finish();
     if (flags & 2) bs.writeByteAlignment();
     *n_bits = bs.getNumberOfWrittenBits();

@@ -102,6 +102,40 @@ int shim_encode_streams(int n_streams, const uint32_t *ops, const long *op_off, 
   }
 }
 
+// GPU: BinEncoderHip in Immediate mode asked getNumWrittenBits() after every `every`-th op (one probing launch per
+// question), with `lead_bits` bits already in its bitstream.  Returns the number of answers.
+long shim_num_written_bits(const uint32_t *ops, long n_ops, int qp, int init_id, int every, int lead_bits, uint32_t *answers,
+                           long cap) {
+  try {
+    HipBatch batch(0);
+    BinEncoderHip enc(batch, BinEncoderHip::Immediate);
+    OutputBitstream bs;
+    if (lead_bits) bs.write((1u << lead_bits) - 1u, uint32_t(lead_bits));
+    enc.init(&bs);
+    enc.reset(qp, init_id);
+    long n = 0;
+    for (long i = 0; i < n_ops; i++) {
+      apply_ops(enc, ops + 4 * i, 1);
+      if ((i + 1) % every == 0 || i + 1 == n_ops) {
+        if (n >= cap) return -3;
+        answers[n++] = enc.getNumWrittenBits();
+      }
+    }
+    BinEncoderHip deferred(batch);   // Deferred mode has nothing coded to ask about: the call throws
+    deferred.init(&bs);
+    deferred.reset(qp, init_id);
+    try {
+      (void)deferred.getNumWrittenBits();
+      return -4;
+    } catch (Exception &) {
+    }
+    return n;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 // GPU: replay-decode one substream: plan the record ids, run, then pull every bin back through the
 // BinDecoderBase-shaped calls.  Returns 0, or -1 with shim_last_error() (e.g. "FIFO exceeded").
 int shim_decode_replay(const uint16_t *rec, long n, int qp, int init_id, const uint8_t *bytes, long n_bytes,

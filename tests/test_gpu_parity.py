@@ -15,17 +15,16 @@ from entropy_coding_amd.workload import CONFIGS, build_batch
 pytestmark = pytest.mark.gpu
 
 
-# kernel variants: 0 = auto, 3 = v3 phased wave (auto below 2 048 substreams), 4 = v4 quad, 5 = v5 three-wave
-# encoder, 6 = v6 three-wave encoder whose output wave rebuilds the code value (the chain wave only runs the range).  The superseded v1 (wave-serial) and v2 (lane-per-substream, 2 | L << 8) are never dispatched to by `auto`;
-# they stay selectable and get one parity pass of their own (test_legacy_variants_still_bit_exact), not the whole matrix.
-VARIANTS = {"auto": 0, "v3": 3, "v4": 4, "v5": 5, "v6": 6, "v7": 7}
-LEGACY_VARIANTS = {"v1": 1, "v2_L4": 2 | (4 << 8)}
+# auto = the dispatch (encode v7 from 3 072 substreams, v6 below; decode v4); 4 / 6 / 7 force one encoder generation
+# (the generations v1-v3 and v5 were retired in round 3: cabac_hip_set_variant refuses them)
+VARIANTS = {"auto": 0, "v4": 4, "v6": 6, "v7": 7}
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
 def hip(request):
     c = H.gpu_ctx()   # raises without a GPU: there is no fallback
-    c.set_variant(VARIANTS[request.param], VARIANTS[request.param])
+    v = VARIANTS[request.param]
+    c.set_variant(v, v if v in (0, 4) else 0)        # one decoder generation is dispatched (v4); DECODE_VARIANTS below
     c.variant_name = request.param
     yield c
     c.close()
@@ -299,26 +298,36 @@ def test_full_size_c5_round_trip_device_api(hip):
     _full_size_round_trip(hip, "C5", 409)
 
 
-def test_legacy_variants_still_bit_exact():
-    """v1 / v2 (never dispatched to, kept selectable): one ragged random batch each against the oracle."""
+def test_probe_reports_num_written_bits(hip):
+    """CABAC_SUB_PROBE: no flush, results[].n_bits = BinEncoderBase::getNumWrittenBits() (arith_codec.cpp:482-485) after the
+    substream's records — the oracle's count (pinned to the reference's by test_oracle_vs_reference.py) for ragged prefixes,
+    empty substreams and long runs of outstanding 0xFF bytes, next to ordinary finished substreams in the same batch."""
     orc = H.load_oracle()
-    rng = np.random.default_rng(77)
-    lens = [0, 1, 17, 5000] + [int(x) for x in rng.integers(0, 3000, size=60)]
-    recs = [H.random_records(rng, max(n - 1, 0), end_trm=(n > 0)) for n in lens]
+    rng = np.random.default_rng(808)
+    recs = [np.zeros(0, np.uint16), np.full(5000, 17, np.uint16), np.full(3000, 17 | 0x8000, np.uint16)]
+    recs += [H.random_records(rng, int(n), ctx_frac=float(rng.choice([0.0, 0.6, 1.0])), end_trm=False) for n in rng.integers(1, 2500, size=90)]
     lens = [len(r) for r in recs]
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(recs)), rng.integers(0, 3, size=len(recs)), 0,
+                              capacities=[int(capi.encode_bound(n, n, n)) for n in lens])
+    probe = np.arange(len(recs)) % 4 != 3
+    desc["init_id"] |= np.where(probe, 0x400, H.SUB_FINISH).astype(np.uint32)
     records = np.concatenate(recs)
-    desc, total = H.make_desc(lens, rng.integers(0, 64, size=len(lens)), rng.integers(0, 3, size=len(lens)),
-                              H.SUB_FINISH | H.SUB_ALIGN_RBSP)
-    for name, v in LEGACY_VARIANTS.items():
+    out, res = hip.encode_batch(desc, records, total)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    assert np.array_equal(res["n_bits"], res_o["n_bits"]) and not res["flags"].any()
+    for s in np.nonzero(~probe)[0]:
+        assert np.array_equal(_stream_bytes(out, desc, res, s), _stream_bytes(out_o, desc, res_o, s)), s
+
+
+def test_retired_variants_are_refused():
+    """Variant numbers of the retired generations fail loudly at launch instead of falling back to another kernel."""
+    desc, total = H.make_desc([4], [30], [2], H.SUB_FINISH)
+    rec = H.random_records(np.random.default_rng(1), 3)
+    for v in (1, 2, 3, 5, 9):
         c = H.gpu_ctx()
-        c.set_variant(v, v)
-        out, res = _compare_encode(c, orc, desc, records, total)
-        dd = desc.copy(); dd["byte_capacity"] = (res["n_bits"] + 7) // 8
-        bins, rd = c.decode_batch(dd, records, out, check=False)
-        bins_o, ro = orc.decode_batch(dd, records, out)
-        assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"]), name
-        assert not rd["flags"][dd["n_records"] > 0].any()
-        assert np.array_equal(bins, bins_o) and np.array_equal(bins, (records >> 15).astype(np.uint8)), name
+        c.set_variant(v, 0)
+        with pytest.raises(capi.CabacHipError):
+            c.encode_batch(desc, rec, total)
         c.close()
 
 
@@ -365,19 +374,6 @@ for n_sub in (37, 4100):
     assert np.array_equal(ef_g, ef_o) and np.array_equal(eb_g[ef_o == 0], eb_o[ef_o == 0])
 print("OK")
 '''
-
-
-@pytest.mark.parametrize("units", [2, 4])
-def test_v5_units_per_workgroup_on_ragged_batches(units):
-    """The encoder's workgroup size (2 or 4 context/chain/output units sharing one barrier) is chosen by batch size;
-    here it is forced (CABAC_V5_UNITS is read once per process, hence the child process) on ragged batches with
-    empty substreams, error flags and an incomplete last workgroup."""
-    import subprocess
-    import sys
-    env = dict(os.environ, CABAC_V5_UNITS=str(units))
-    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT, "enc": 5}
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("enc", [0, 6, 7])

@@ -317,6 +317,28 @@ def test_shim_encode_matches_reference_golden(drv):
 
 
 @pytest.mark.gpu
+def test_shim_get_num_written_bits_immediate_mode(drv):
+    """BinEncoderHip::getNumWrittenBits() in Immediate mode (arith_codec.cpp:482-485): after every few calls the answer is the
+    oracle's — pinned to the reference's own getNumWrittenBits() by tests/test_oracle_vs_reference.py — plus the bits the
+    bitstream held before; Deferred mode throws."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(93)
+    drv.shim_num_written_bits.restype = ctypes.c_long
+    drv.shim_num_written_bits.argtypes = [u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p, ctypes.c_long]
+    for lead, every in ((0, 7), (5, 40)):
+        ops = H.random_ops(rng, 280, ctx_frac=0.6, end_trm=False, with_align=True)
+        ans = np.zeros(len(ops), np.uint32)
+        n = drv.shim_num_written_bits(H._ptr(ops, u32p), len(ops), 28, 2, every, lead, H._ptr(ans, u32p), len(ans))
+        assert n > 0, drv.shim_last_error()
+        marks = [i + 1 for i in range(len(ops)) if (i + 1) % every == 0 or i + 1 == len(ops)]
+        assert n == len(marks)
+        for k, m in enumerate(marks):
+            rec = orc.ops_to_records(ops[:m])
+            _, want = orc.encode_records(rec, 28, 2, 4)
+            assert int(ans[k]) == lead + want, (lead, every, m)
+
+
+@pytest.mark.gpu
 def test_shim_decode_replay(drv):
     orc = H.load_oracle()
     rng = np.random.default_rng(91)

@@ -59,6 +59,25 @@ def test_encode_ops_bit_exact(seed):
     assert xbits == fbits and np.array_equal(xb, fb)
 
 
+def test_num_written_bits_probe():
+    """flags bit 2 (CABAC_SUB_PROBE on the device): the oracle's count against the reference's own
+    BinEncoderBase::getNumWrittenBits() (arith_codec.cpp:482-485) at many points along bin strings, long 0xFF runs included
+    (buffered bytes count)."""
+    ref, orc = H.load_ref(), H.load_oracle()
+    rng = np.random.default_rng(4321)
+    for trial in range(40):
+        if trial % 5 == 4:      # an all-MPS single-context stream: long runs of outstanding bytes
+            rec = np.full(4000, 17 | (0x8000 if trial & 1 else 0), np.uint16)
+        else:
+            rec = H.random_records(rng, int(rng.integers(1, 3000)), ctx_frac=float(rng.choice([0.0, 0.5, 0.9, 1.0])), end_trm=False)
+        qp, init_id = int(rng.integers(0, 64)), int(rng.integers(0, 3))
+        for m in sorted(set([0, 1, 2, len(rec)] + [int(x) for x in rng.integers(0, len(rec) + 1, size=12)])):
+            _, rbits = ref.encode_records(rec[:m], qp, init_id, 4)
+            _, obits = orc.encode_records(rec[:m], qp, init_id, 4)
+            assert rbits == obits, (trial, m)
+    assert orc.encode_records(np.zeros(0, np.uint16), 30, 2, 4)[1] == 0
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_decode_records_and_ops(seed):
     ref, orc = H.load_ref(), H.load_oracle()

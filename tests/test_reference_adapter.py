@@ -98,6 +98,25 @@ def test_reference_cabacwriter_on_gpu_estimator_matches_bitestimator_std(adp, se
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.gpu
+def test_get_num_written_bits_matches_bin_encoder_std(adp):
+    """getNumWrittenBits() (arith_codec.cpp:482-485, what estBits asks for): the reference's BinEncoder_Std and BinEncoderHipRef
+    in Immediate mode (one probing launch per question) give the same answers all along a substream."""
+    rng = np.random.default_rng(41)
+    f = adp.adapter_num_written_bits
+    f.restype = ctypes.c_long
+    f.argtypes = [ctypes.c_int, H.u32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, H.u32p, ctypes.c_long]
+    for lead, every in ((0, 5), (3, 33)):
+        ops = H.random_ops(rng, 300, ctx_frac=0.65, end_trm=False, with_align=True)
+        got = []
+        for which in (0, 1):
+            ans = np.zeros(len(ops), np.uint32)
+            n = f(which, H._ptr(ops, H.u32p), len(ops), 33, 1, every, lead, H._ptr(ans, H.u32p), len(ans))
+            assert n > 0, adp.adapter_last_error()
+            got.append(ans[:n].copy())
+        assert np.array_equal(got[0], got[1]) and got[0][-1] > lead
+
+
 def _residual(adp, which, blocks, comps, rig_flags, qp=32):
     wh = np.array([[c.shape[1], c.shape[0]] for c in blocks], np.int32).ravel()
     comp = np.array(comps, np.int32)
