@@ -39,9 +39,12 @@ struct cabac_hip_ctx {
   std::vector<int32_t> prof_kind;
   uint32_t prof_n = 0;
   // device staging for the host-pointer entry points (grown on demand)
-  // [5]: scratch of the residual binariser, [6]: compacted payload, [7]: payload offsets
-  void *d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // [5]: scratch of the residual binariser, [6]: compacted payload, [7]: payload offsets; [8..]: the spliced-residual path
+  // (kSp* below)
+  static constexpr int kSlots = 24;
+  void *d_buf[kSlots] = {};
+  size_t d_cap[kSlots] = {};
+  void *h_totals = nullptr;  // pinned, 64 bytes: what the spliced-residual path reads back in the middle
   // ---- the PCIe path of the host-pointer entry points -------------------------------------------------
   static constexpr int kKernelStreams = 4, kMaxChunks = 8, kBounceDepth = 4;
   static constexpr size_t kBounceBlock = size_t(4) << 20;
@@ -178,7 +181,7 @@ bool host_is_pinned(const void *p, size_t bytes) {
 // host-pointer call must leave behind when it returns early (the blocks' destinations point into the caller's buffers,
 // which the caller may free as soon as the call has returned — they are dropped, not copied).
 void pipe_quiesce(cabac_hip_ctx *c) {
-  for (hipStream_t st : {c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
+  for (hipStream_t st : {c->stream, c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
     if (st) (void)hipStreamSynchronize(st);
   for (cabac_hip_ctx::Bounce *b : {&c->bounce_in, &c->bounce_out})
     for (int i = 0; i < cabac_hip_ctx::kBounceDepth; i++) {
@@ -415,8 +418,9 @@ void cabac_hip_destroy(cabac_hip_ctx *c) {
   if (!c) return;
   DeviceGuard g(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < cabac_hip_ctx::kSlots; i++)
     if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
+  if (c->h_totals) (void)hipHostFree(c->h_totals);
   pipe_destroy(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -974,6 +978,199 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
     if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
+}
+
+// ---- coefficients -> bytes (cabac_splice.hip) -------------------------------------------------------------------
+namespace {
+// device slots of the spliced-residual path
+enum { kSpCnt = 8, kSpPlan = 9, kSpDesc = 10, kSpTuOff = 11, kSpRec = 12, kSpBytes = 13, kSpFlag = 14,
+       // ... and the staging of its host-pointer form
+       kSpInDesc = 15, kSpInRec = 16, kSpInFirst = 17, kSpInSplice = 18, kSpInTu = 19, kSpInCoeff = 20, kSpOutRes = 21,
+       kSpOutInfo = 22, kSpOutCnt = 23 };
+
+struct Timed {  // profile-ring bracket around a group of launches (nothing when the ring is off or full)
+  cabac_hip_ctx *c;
+  Bracket br{nullptr, nullptr};
+  Timed(cabac_hip_ctx *ctx, int kind) : c(ctx) {
+    if (!c->prof_ev.empty() && c->prof_n < c->prof_kind.size()) {
+      br = bracket_for(c, kind);
+      (void)hipEventRecord(br.a, c->stream);
+    }
+  }
+  ~Timed() {
+    if (br.b) (void)hipEventRecord(br.b, c->stream);
+  }
+};
+}  // namespace
+
+int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                                     const uint32_t *d_splice_first, const cabac_splice *d_splices, uint32_t n_splice, uint32_t n_tu,
+                                     const cabac_tu_desc *d_tu, const int32_t *d_coeff, uint8_t *d_payload, uint64_t payload_capacity,
+                                     uint64_t *d_payload_offsets, cabac_substream_result *d_results, uint32_t *d_tu_info,
+                                     uint32_t *d_bin_counts) {
+  if (!c || !d_payload_offsets || (n_sub && (!d_desc || !d_records || !d_splice_first || !d_payload || !d_results)) ||
+      (n_splice && !d_splices) || (n_tu && (!d_tu || !d_coeff)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  if (n_splice != n_tu) return fail(c, CABAC_HIP_ERR_INVALID, "every block must be spliced exactly once (n_splice != n_tu)");
+  DeviceGuard g(c->device);
+  int rc;
+  const size_t n_pre = size_t(n_splice) + n_sub + 1;
+  const size_t plan32 = n_pre + 2 * size_t(n_sub) + size_t(n_tu ? n_tu : 1) + 2;  // pre, sub_n, sub_cap, seen, err (+ pad)
+  const size_t plan32_pad = (plan32 + 1) & ~size_t(1);
+  if ((rc = ensure(c, kSpCnt, 2 * size_t(n_tu ? n_tu : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, 5, cabac::residual_scratch_bytes(n_tu)))) return rc;
+  if ((rc = ensure(c, kSpPlan, plan32_pad * sizeof(uint32_t) + (2 * size_t(n_sub) + 3) * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, kSpDesc, size_t(n_sub ? n_sub : 1) * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, kSpTuOff, size_t(n_tu ? n_tu : 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, kSpFlag, 64))) return rc;
+  if (!c->h_totals) HIP_TRY(c, hipHostMalloc(&c->h_totals, 64, hipHostMallocDefault));
+  uint32_t *d_cnt = static_cast<uint32_t *>(c->d_buf[kSpCnt]), *d_info = d_cnt + (n_tu ? n_tu : 1);
+  uint32_t *pre = static_cast<uint32_t *>(c->d_buf[kSpPlan]), *sub_n = pre + n_pre, *sub_cap = sub_n + n_sub, *seen = sub_cap + n_sub,
+           *err = seen + (n_tu ? n_tu : 1);
+  uint64_t *rec_base = reinterpret_cast<uint64_t *>(pre + plan32_pad), *byte_base = rec_base + n_sub, *totals = byte_base + n_sub;
+  auto *desc2 = static_cast<cabac_substream_desc *>(c->d_buf[kSpDesc]);
+  auto *tu_off = static_cast<uint64_t *>(c->d_buf[kSpTuOff]);
+  c->timed = false;
+  {  // block sizes (pass 1 of the binariser)
+    Timed t(c, 5);
+    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, nullptr, d_cnt, d_info, nullptr, c->d_buf[5]));
+  }
+  {
+    Timed t(c, 10);
+    HIP_TRY(c, cabac::launch_splice_plan(c->stream, n_sub, n_tu, d_desc, d_splice_first, d_splices, d_cnt, pre, sub_n, sub_cap, seen, err,
+                                         rec_base, byte_base, totals));
+  }
+  uint64_t *h_tot = static_cast<uint64_t *>(c->h_totals);
+  HIP_TRY(c, hipMemcpyAsync(h_tot, totals, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the one wait: sizes decide the buffers of the second half
+  if (h_tot[2]) return fail(c, CABAC_HIP_ERR_INVALID, "splice list: not sorted, outside its substream, or a block not spliced exactly once");
+  if ((rc = ensure(c, kSpRec, (h_tot[0] + 64) * sizeof(uint16_t)))) return rc;
+  if ((rc = ensure(c, kSpBytes, h_tot[1] + 64))) return rc;
+  auto *exp_rec = static_cast<uint16_t *>(c->d_buf[kSpRec]);
+  auto *slots = static_cast<uint8_t *>(c->d_buf[kSpBytes]);
+  {
+    Timed t(c, 10);
+    HIP_TRY(c, cabac::launch_splice_expand(c->stream, n_sub, d_desc, d_records, d_splice_first, d_splices, pre, sub_n, sub_cap, rec_base,
+                                           byte_base, desc2, tu_off, exp_rec));
+  }
+  {  // block records (pass 2), straight into the expanded substreams
+    Timed t(c, 5);
+    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, tu_off, d_cnt, d_info, exp_rec, c->d_buf[5]));
+  }
+  {
+    Timed t(c, 0);
+    HIP_TRY(c, cabac::launch_encode(c->stream, c->enc_variant, n_sub, desc2, exp_rec, slots, d_results));
+  }
+  if (d_bin_counts) {
+    Timed t(c, 11);
+    HIP_TRY(c, cabac::launch_bin_count(c->stream, n_sub, desc2, exp_rec, d_bin_counts));
+  }
+  {
+    Timed t(c, 6);
+    HIP_TRY(c, cabac::launch_assemble(c->stream, n_sub, desc2, d_results, slots, d_payload, payload_capacity, d_payload_offsets));
+  }
+  if (d_tu_info && n_tu) HIP_TRY(c, hipMemcpyAsync(d_tu_info, d_info, size_t(n_tu) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  return CABAC_HIP_OK;
+}
+
+static int encode_batch_residual_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                      uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
+                                      const cabac_tu_desc *tus, const int32_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                      uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
+                                      uint32_t *tu_info, uint32_t *bin_counts) {
+  if (!c || !payload_offsets || (n_sub && (!desc || !splice_first || !results || !payload)) || (n_tu && (!tus || !coeff || !splices)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  payload_offsets[0] = 0;
+  if (n_sub == 0) return n_tu ? fail(c, CABAC_HIP_ERR_INVALID, "blocks without a substream") : CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    if (desc[s].rec_offset > n_records_total || desc[s].n_records > n_records_total - desc[s].rec_offset)
+      return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if ((desc[s].init_id & 3u) > 2u) return fail(c, CABAC_HIP_ERR_INVALID, "init_id must be 0..2");
+    if (splice_first[s] > splice_first[s + 1]) return fail(c, CABAC_HIP_ERR_INVALID, "splice_first must not decrease");
+  }
+  const uint32_t n_splice = splice_first[n_sub];
+  if (splice_first[0] != 0 || n_splice != n_tu) return fail(c, CABAC_HIP_ERR_INVALID, "every block must be spliced exactly once");
+  DeviceGuard g(c->device);
+  int rc;
+  if ((rc = pipe_init(c))) return rc;
+  const size_t first_bytes = (size_t(n_sub) + 1) * sizeof(uint32_t);
+  if ((rc = ensure(c, kSpInDesc, n_sub * sizeof(cabac_substream_desc)))) return rc;
+  if ((rc = ensure(c, kSpInRec, (n_records_total + 8) * sizeof(uint16_t)))) return rc;
+  if ((rc = ensure(c, kSpInFirst, first_bytes))) return rc;
+  if ((rc = ensure(c, kSpInSplice, size_t(n_splice ? n_splice : 1) * sizeof(cabac_splice)))) return rc;
+  if ((rc = ensure(c, kSpInTu, size_t(n_tu ? n_tu : 1) * sizeof(cabac_tu_desc)))) return rc;
+  if ((rc = ensure(c, kSpInCoeff, (n_coeff_total + 4) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, kSpOutRes, n_sub * sizeof(cabac_substream_result)))) return rc;
+  if ((rc = ensure(c, kSpOutInfo, size_t(n_tu ? n_tu : 1) * sizeof(uint32_t)))) return rc;
+  if (bin_counts && (rc = ensure(c, kSpOutCnt, size_t(n_sub) * CABAC_BIN_COUNT_WORDS * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, 6, payload_capacity ? payload_capacity : 16))) return rc;
+  if ((rc = ensure(c, 7, (size_t(n_sub) + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, kSpFlag, 64))) return rc;
+  const size_t res_bytes = size_t(n_sub) * sizeof(cabac_substream_result), off_bytes = (size_t(n_sub) + 1) * sizeof(uint64_t);
+  if ((rc = ensure_pinned(c, 0, res_bytes + off_bytes + 64))) return rc;
+  auto *h_res = static_cast<cabac_substream_result *>(c->h_pin[0]);
+  auto *h_off = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(c->h_pin[0]) + res_bytes);
+  auto *h_flag = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(h_off) + off_bytes);
+  uint32_t *d_flag = static_cast<uint32_t *>(c->d_buf[kSpFlag]);  // [0] descriptor range check, [1] empty / bad block
+
+  // what came before on the caller's stream is finished first; uploads run on the copy stream, the kernels on the ctx's
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // small things first: the block descriptors are checked on the device while the coefficients are still on the wire
+  if ((rc = h2d(c, c->d_buf[kSpInTu], tus, size_t(n_tu) * sizeof(cabac_tu_desc), c->s_in))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev_in[0], c->s_in));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in[0], 0));
+  HIP_TRY(c, cabac::launch_tu_range_check(c->stream, n_tu, static_cast<const cabac_tu_desc *>(c->d_buf[kSpInTu]), n_coeff_total, d_flag));
+  HIP_TRY(c, hipMemcpyAsync(h_flag, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_k[0], c->stream));
+  if ((rc = h2d(c, c->d_buf[kSpInDesc], desc, n_sub * sizeof(cabac_substream_desc), c->s_in))) return rc;
+  if ((rc = h2d(c, c->d_buf[kSpInFirst], splice_first, first_bytes, c->s_in))) return rc;
+  if ((rc = h2d(c, c->d_buf[kSpInSplice], splices, size_t(n_splice) * sizeof(cabac_splice), c->s_in))) return rc;
+  if ((rc = h2d(c, c->d_buf[kSpInRec], records, n_records_total * sizeof(uint16_t), c->s_in))) return rc;
+  if ((rc = h2d(c, c->d_buf[kSpInCoeff], coeff, n_coeff_total * sizeof(int32_t), c->s_in))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev_in[1], c->s_in));
+  HIP_TRY(c, hipEventSynchronize(c->ev_k[0]));
+  if (*h_flag) return fail(c, CABAC_HIP_ERR_INVALID, "coefficients out of range");
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in[1], 0));
+  rc = cabac_hip_encode_residual_device(c, n_sub, static_cast<const cabac_substream_desc *>(c->d_buf[kSpInDesc]),
+                                        static_cast<const uint16_t *>(c->d_buf[kSpInRec]), static_cast<const uint32_t *>(c->d_buf[kSpInFirst]),
+                                        static_cast<const cabac_splice *>(c->d_buf[kSpInSplice]), n_splice, n_tu,
+                                        static_cast<const cabac_tu_desc *>(c->d_buf[kSpInTu]), static_cast<const int32_t *>(c->d_buf[kSpInCoeff]),
+                                        static_cast<uint8_t *>(c->d_buf[6]), payload_capacity, static_cast<uint64_t *>(c->d_buf[7]),
+                                        static_cast<cabac_substream_result *>(c->d_buf[kSpOutRes]), static_cast<uint32_t *>(c->d_buf[kSpOutInfo]),
+                                        bin_counts ? static_cast<uint32_t *>(c->d_buf[kSpOutCnt]) : nullptr);
+  if (rc) return rc;
+  HIP_TRY(c, cabac::launch_tu_info_any(c->stream, n_tu, static_cast<const uint32_t *>(c->d_buf[kSpOutInfo]), d_flag + 1));
+  HIP_TRY(c, hipMemcpyAsync(h_res, c->d_buf[kSpOutRes], res_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h_off, c->d_buf[7], off_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h_flag, d_flag + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_k[1], c->stream));
+  // the big things leave on the outgoing copy stream once the offsets are known
+  HIP_TRY(c, hipEventSynchronize(c->ev_k[1]));
+  const uint64_t n_pay = h_off[n_sub];
+  if (n_pay > payload_capacity) return fail(c, CABAC_HIP_ERR_INVALID, "payload_capacity too small");
+  if ((rc = d2h(c, payload, c->d_buf[6], n_pay, c->s_out))) return rc;
+  if (tu_info && (rc = d2h(c, tu_info, c->d_buf[kSpOutInfo], size_t(n_tu) * sizeof(uint32_t), c->s_out))) return rc;
+  if (bin_counts && (rc = d2h(c, bin_counts, c->d_buf[kSpOutCnt], size_t(n_sub) * CABAC_BIN_COUNT_WORDS * sizeof(uint32_t), c->s_out))) return rc;
+  if ((rc = d2h_drain(c))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->s_out));
+  int status = *h_flag ? CABAC_HIP_ERR_SUBSTREAM : CABAC_HIP_OK;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    results[s] = h_res[s];
+    payload_offsets[s + 1] = h_off[s + 1];
+    if (h_res[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+  }
+  if (status) c->last_error = "substream flag set, or an empty / badly described block (see results[].flags, tu_info[])";
+  return status;
+}
+
+int cabac_hip_encode_batch_residual(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                    uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
+                                    const cabac_tu_desc *tus, const int32_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                    uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
+                                    uint32_t *tu_info, uint32_t *bin_counts) {
+  return host_call_exit(c, encode_batch_residual_impl(c, n_sub, desc, records, n_records_total, splice_first, splices, n_tu, tus, coeff,
+                                                      n_coeff_total, payload, payload_capacity, payload_offsets, results, tu_info,
+                                                      bin_counts));
 }
 
 // ---- pinned host memory for the caller's buffers ------------------------------------------------------------

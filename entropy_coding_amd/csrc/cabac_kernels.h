@@ -50,6 +50,21 @@ hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_sub
                                  const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff, uint32_t *tu_info,
                                  cabac_substream_result *results);
 
+// residual records spliced into host-recorded substreams (cabac_splice.hip); array sizes: pre n_splice + n_sub + 1,
+// sub_n / sub_cap / rec_base / byte_base n_sub, seen n_tu, err 1, totals 3 ({records, bytes, error})
+hipError_t launch_splice_plan(hipStream_t st, uint32_t n_sub, uint32_t n_tu, const cabac_substream_desc *desc,
+                              const uint32_t *splice_first, const cabac_splice *splices, const uint32_t *tu_n_records,
+                              uint32_t *pre, uint32_t *sub_n, uint32_t *sub_cap, uint32_t *seen, uint32_t *err, uint64_t *rec_base,
+                              uint64_t *byte_base, uint64_t *totals);
+hipError_t launch_splice_expand(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *host_records,
+                                const uint32_t *splice_first, const cabac_splice *splices, const uint32_t *pre,
+                                const uint32_t *sub_n, const uint32_t *sub_cap, const uint64_t *rec_base, const uint64_t *byte_base,
+                                cabac_substream_desc *desc_out, uint64_t *tu_offset, uint16_t *records);
+hipError_t launch_tu_range_check(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, uint64_t n_coeff_total, uint32_t *err);
+hipError_t launch_tu_info_any(hipStream_t st, uint32_t n_tu, const uint32_t *info, uint32_t *flag);
+hipError_t launch_bin_count(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                            uint32_t *counts);
+
 // substream assembly (cabac_assemble.hip)
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,

@@ -165,6 +165,18 @@ void BinCounter::reset() {
   m_NumBinsTrm = 0;
 }
 
+void BinCounter::snapshot(uint32_t *out) const {
+  std::copy(m_NumBinsCtx.begin(), m_NumBinsCtx.end(), out);
+  out[CABAC_NUM_CONTEXTS] = m_NumBinsEP;
+  out[CABAC_NUM_CONTEXTS + 1] = m_NumBinsTrm;
+}
+
+void BinCounter::addFromDevice(const uint32_t *counts, const uint32_t *host) {
+  for (unsigned k = 0; k < CABAC_NUM_CONTEXTS; k++) m_NumBinsCtx[k] += counts[k] - host[k];
+  m_NumBinsEP += counts[CABAC_NUM_CONTEXTS] - host[CABAC_NUM_CONTEXTS];
+  m_NumBinsTrm += counts[CABAC_NUM_CONTEXTS + 1] - host[CABAC_NUM_CONTEXTS + 1];
+}
+
 uint32_t BinCounter::getAll() const {
   uint32_t count = m_NumBinsEP + m_NumBinsTrm;
   for (uint32_t c : m_NumBinsCtx) count += c;
@@ -194,13 +206,56 @@ cabac_hip_ctx *HipBatch::handle() {
   return m_ctx;
 }
 
+cabac_tu_desc makeTuDesc(const HipBatch::ResidualBlock &b, uint64_t coeff_offset) {
+  unsigned lw = 0, lh = 0;
+  while ((1u << lw) < b.width) lw++;
+  while ((1u << lh) < b.height) lh++;
+  if ((1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6)
+    throw Exception("residual: block sizes must be powers of two up to 64");
+  cabac_tu_desc t{};
+  t.coeff_offset = coeff_offset;
+  t.log2_width = uint8_t(lw);
+  t.log2_height = uint8_t(lh);
+  t.channel = b.chroma ? 1 : 0;
+  t.flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
+                    (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
+                    (b.transformSkip && b.bdpcm ? CABAC_TU_BDPCM : 0u));
+  t.max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
+  return t;
+}
+
+uint64_t HipBatch::stageCoefficients(const int32_t *coeff, size_t n) {
+  const uint64_t at = m_stageCoeff.size();
+  m_stageCoeff.insert(m_stageCoeff.end(), coeff, coeff + n);
+  m_stagedBlocksOpen++;
+  return at;
+}
+
+// the coded substream into its container, leaving it as the reference's finish() leaves its bitstream
+void HipBatch::deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits) {
+  const uint32_t whole = nbits / 8, tail = nbits & 7;
+  if (p.deliver) p.deliver(src, whole, tail);
+  OutputBitstream *sink = p.sink;
+  if (!sink) return;
+  if (sink->m_num_held_bits == 0) {
+    sink->m_fifo.insert(sink->m_fifo.end(), src, src + whole);
+  } else {
+    for (uint32_t i = 0; i < whole; i++) sink->write(src[i], 8);
+  }
+  if (tail) sink->write(uint32_t(src[whole]) >> (8 - tail), tail);
+}
+
 void HipBatch::flush() {
   if (m_pending.empty()) return;
-  const uint32_t n = uint32_t(m_pending.size());
+  std::vector<Pending> done;
+  done.swap(m_pending);
+  for (const Pending &p : done)
+    if (!p.blocks.empty()) return flushSpliced(done);
+  const uint32_t n = uint32_t(done.size());
   std::vector<cabac_substream_desc> desc(n);
   uint64_t rec_total = 0, byte_total = 0;
   for (uint32_t s = 0; s < n; s++) {
-    Pending &p = m_pending[s];
+    Pending &p = done[s];
     desc[s].rec_offset = rec_total;
     desc[s].byte_offset = byte_total;
     desc[s].n_records = uint32_t(p.records.size());
@@ -215,26 +270,73 @@ void HipBatch::flush() {
   if (records.size() < rec_total + 1) records.resize(rec_total + 1);
   if (bytes.size() < byte_total + 1) bytes.resize(byte_total + 1);
   for (uint32_t s = 0; s < n; s++)
-    if (!m_pending[s].records.empty())
-      std::memcpy(records.data() + desc[s].rec_offset, m_pending[s].records.data(), m_pending[s].records.size() * 2);
+    if (!done[s].records.empty())
+      std::memcpy(records.data() + desc[s].rec_offset, done[s].records.data(), done[s].records.size() * 2);
   std::vector<cabac_substream_result> res(n);
   int rc = cabac_hip_encode_batch(handle(), n, desc.data(), records.data(), rec_total, bytes.data(), byte_total,
                                   res.data());
-  std::vector<Pending> done;
-  done.swap(m_pending);
   check_status(m_ctx, rc, "cabac_hip_encode_batch");
+  for (uint32_t s = 0; s < n; s++) deliverBytes(done[s], bytes.data() + desc[s].byte_offset, res[s].n_bits);
+}
+
+// at least one substream has residual blocks to be spliced in on the device: coefficients -> bytes
+// (cabac_hip_encode_batch_residual; the bins of residual_coding go "straight into the encoder", cabac_writer.cpp:2424-2525)
+void HipBatch::flushSpliced(std::vector<Pending> &done) {
+  const uint32_t n = uint32_t(done.size());
+  std::vector<cabac_substream_desc> desc(n);
+  std::vector<uint32_t> first(size_t(n) + 1, 0);
+  std::vector<cabac_splice> splices;
+  std::vector<cabac_tu_desc> tus;
+  uint64_t rec_total = 0, n_blocks = 0;
+  bool want_counts = false;
   for (uint32_t s = 0; s < n; s++) {
-    OutputBitstream *sink = done[s].sink;
-    const uint8_t *src = bytes.data() + desc[s].byte_offset;
-    const uint32_t nbits = res[s].n_bits, whole = nbits / 8, tail = nbits & 7;
-    if (done[s].deliver) done[s].deliver(src, whole, tail);
-    if (!sink) continue;
-    if (sink->m_num_held_bits == 0) {
-      sink->m_fifo.insert(sink->m_fifo.end(), src, src + whole);
-    } else {
-      for (uint32_t i = 0; i < whole; i++) sink->write(src[i], 8);
-    }
-    if (tail) sink->write(uint32_t(src[whole]) >> (8 - tail), tail);
+    Pending &p = done[s];
+    desc[s] = cabac_substream_desc{};
+    desc[s].rec_offset = rec_total;
+    desc[s].n_records = uint32_t(p.records.size());
+    desc[s].qp = p.qp;
+    desc[s].init_id = uint32_t(p.initId) | CABAC_SUB_FINISH;
+    rec_total += p.records.size();
+    for (const cabac_splice &sp : p.splices) splices.push_back(cabac_splice{sp.at, uint32_t(tus.size()) + sp.tu});
+    tus.insert(tus.end(), p.blocks.begin(), p.blocks.end());
+    first[s + 1] = uint32_t(splices.size());
+    n_blocks += p.blocks.size();
+    want_counts = want_counts || bool(p.counted);
+  }
+  RecordVector &records = m_stageRecords;
+  if (records.size() < rec_total + 1) records.resize(rec_total + 1);
+  for (uint32_t s = 0; s < n; s++)
+    if (!done[s].records.empty())
+      std::memcpy(records.data() + desc[s].rec_offset, done[s].records.data(), done[s].records.size() * 2);
+  std::vector<cabac_substream_result> res(n);
+  std::vector<uint64_t> offsets(size_t(n) + 1, 0);
+  std::vector<uint32_t> info(tus.size() ? tus.size() : 1, 0), counts(want_counts ? size_t(n) * CABAC_BIN_COUNT_WORDS : 0);
+  // The coded size is only known on the device.  A first guess from the input sizes; the call says when it does not fit.
+  size_t capacity = std::max<size_t>(size_t(1) << 16, rec_total + m_stageCoeff.size() / 2);
+  int rc = CABAC_HIP_OK;
+  for (int attempt = 0; attempt < 6; attempt++) {
+    if (m_stageBytes.size() < capacity) m_stageBytes.resize(capacity);
+    rc = cabac_hip_encode_batch_residual(handle(), n, desc.data(), records.data(), rec_total, first.data(), splices.data(),
+                                         uint32_t(tus.size()), tus.data(), m_stageCoeff.data(), m_stageCoeff.size(), m_stageBytes.data(),
+                                         m_stageBytes.size(), offsets.data(), res.data(), info.data(),
+                                         want_counts ? counts.data() : nullptr);
+    if (rc != CABAC_HIP_ERR_INVALID || std::string(cabac_hip_last_error(m_ctx)) != "payload_capacity too small") break;
+    capacity *= 4;
+  }
+  m_stagedBlocksOpen -= std::min<size_t>(m_stagedBlocksOpen, size_t(n_blocks));
+  if (m_stagedBlocksOpen == 0) m_stageCoeff.clear();  // (blocks of encoders still recording keep their place otherwise)
+  if (rc == CABAC_HIP_ERR_SUBSTREAM)
+    for (uint32_t t = 0; t < tus.size(); t++)
+      if (info[t] & CABAC_TU_INFO_EMPTY) throw Exception("Coefficient coding called for empty TU");
+  check_status(m_ctx, rc, "cabac_hip_encode_batch_residual");
+  size_t t0 = 0;
+  for (uint32_t s = 0; s < n; s++) {
+    Pending &p = done[s];
+    if (p.blockInfo)
+      for (size_t k = 0; k < p.blocks.size(); k++) p.blockInfo(k, info[t0 + k]);
+    t0 += p.blocks.size();
+    if (p.counted) p.counted(counts.data() + size_t(s) * CABAC_BIN_COUNT_WORDS, p.hostCounts.data());
+    deliverBytes(p, m_stageBytes.data() + offsets[s], res[s].n_bits);
   }
 }
 
@@ -284,20 +386,8 @@ HipBatch::ResidualResult HipBatch::residual(const std::vector<ResidualBlock> &bl
   uint64_t total = 0;
   for (uint32_t t = 0; t < n; t++) {
     const ResidualBlock &b = blocks[t];
-    unsigned lw = 0, lh = 0;
-    while ((1u << lw) < b.width) lw++;
-    while ((1u << lh) < b.height) lh++;
-    if (!b.coeff || (1u << lw) != b.width || (1u << lh) != b.height || lw > 6 || lh > 6)
-      throw Exception("residual: block sizes must be powers of two up to 64");
-    tus[t] = cabac_tu_desc{};
-    tus[t].coeff_offset = total;
-    tus[t].log2_width = uint8_t(lw);
-    tus[t].log2_height = uint8_t(lh);
-    tus[t].channel = b.chroma ? 1 : 0;
-    tus[t].flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
-                           (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
-                           (b.transformSkip && b.bdpcm ? CABAC_TU_BDPCM : 0u));
-    tus[t].max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
+    if (!b.coeff) throw Exception("residual: block without coefficients");
+    tus[t] = makeTuDesc(b, total);
     total += uint64_t(b.width) * b.height;
   }
   std::vector<int32_t> coeff(total);
@@ -424,7 +514,18 @@ void HipBatch::decode(const std::vector<DecodeJob> &jobs, std::vector<std::vecto
 // ------------------------------------------------------------------ BinEncoderHip
 void BinEncoderHip::start() {
   m_records.clear();
+  m_splices.clear();
+  m_blocks.clear();
   BinCounter::reset();
+}
+
+void BinEncoderHip::encodeResidual(const HipBatch::ResidualBlock &b) {
+  if (!b.coeff) fail("encodeResidual: block without coefficients");
+  if (b.tsFlag) fail("encodeResidual: code transform_skip_flag with encodeBin before the block (tsFlag must be false)");
+  cabac_tu_desc t = makeTuDesc(b, 0);
+  t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height);
+  m_splices.push_back(cabac_splice{uint32_t(m_records.size()), uint32_t(m_blocks.size())});
+  m_blocks.push_back(t);
 }
 
 void BinEncoderHip::restart() {
@@ -508,6 +609,7 @@ void BinEncoderHip::encodeRemAbsEP(unsigned bins, unsigned goRicePar, unsigned c
 unsigned BinEncoderHip::getNumWrittenBits() {
   if (m_mode != Immediate) fail("getNumWrittenBits: nothing is coded before HipBatch::flush() in Deferred mode");
   if (!m_Bitstream) fail("getNumWrittenBits: no bitstream (init not called)");
+  if (!m_blocks.empty()) fail("getNumWrittenBits: the bins of spliced residual blocks are not known before flush()");
   return m_Bitstream->getNumberOfWrittenBits() + m_batch.numWrittenBits(m_records.data(), m_records.size(), m_qp, m_initId);
 }
 
@@ -528,6 +630,14 @@ void BinEncoderHip::finish() {
   p.nTrm = BinCounter::getTrm();
   p.nCtx = BinCounter::getAll() - p.nEp - p.nTrm;
   p.sink = m_Bitstream;
+  if (!m_blocks.empty()) {
+    p.splices.swap(m_splices);
+    p.blocks.swap(m_blocks);
+    p.hostCounts.resize(CABAC_BIN_COUNT_WORDS);
+    BinCounter::snapshot(p.hostCounts.data());
+    BinCounter *counter = this;  // the spliced blocks' bins are counted when the device has told how many there were
+    p.counted = [counter](const uint32_t *counts, const uint32_t *host) { counter->addFromDevice(counts, host); };
+  }
   m_batch.submit(std::move(p));
   if (m_mode == Immediate) m_batch.flush();
 }

@@ -125,6 +125,10 @@ public:
   void addEP(unsigned num) { m_NumBinsEP += num; }
   void addEP() { m_NumBinsEP++; }
   void addTrm() { m_NumBinsTrm++; }
+  // counts that only became known on the device (the bins of spliced residual blocks, HipBatch::flush): `counts` holds
+  // CABAC_BIN_COUNT_WORDS words as cabac_hip_encode_batch_residual reports them, `host` the part already counted here
+  void addFromDevice(const uint32_t *counts, const uint32_t *host);
+  void snapshot(uint32_t *out) const;  // CABAC_BIN_COUNT_WORDS words: per context, bypass, terminate
   uint32_t getAll() const;
   uint32_t getCtx(unsigned ctxId) const { return m_NumBinsCtx[ctxId]; }
   uint32_t getEP() const { return m_NumBinsEP; }
@@ -213,6 +217,11 @@ public:
   };
   std::vector<std::vector<int32_t>> residualParse(const std::vector<ParseJob> &jobs, std::vector<uint32_t> *info = nullptr);
 
+  // Coefficients of blocks whose bins are spliced into a substream on the device (BinEncoderHip::encodeResidual): one
+  // staging area per batch (page-locked under usePinnedMirrors), so that a flush hands the C ABI one contiguous region.
+  // Returns the offset (in coefficients) of the copy.
+  uint64_t stageCoefficients(const int32_t *coeff, size_t n);
+
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
   // integration/reference_adapter.hpp) receives the result: `whole` bytes + `tail_bits` (MSB-aligned
@@ -223,6 +232,12 @@ public:
     uint64_t nCtx = 0, nEp = 0, nTrm = 0;
     OutputBitstream *sink = nullptr;
     std::function<void(const uint8_t *bytes, uint32_t whole, uint32_t tail_bits)> deliver;
+    // residual blocks whose records the device splices in (cabac_hip_encode_batch_residual): splices[k].tu indexes blocks
+    std::vector<cabac_splice> splices;
+    std::vector<cabac_tu_desc> blocks;          // coeff_offset: into the batch's coefficient staging
+    std::vector<uint32_t> hostCounts;           // BinCounter of the host-recorded bins (CABAC_BIN_COUNT_WORDS), if counted is set
+    std::function<void(const uint32_t *counts, const uint32_t *host)> counted;  // the substream's totals, once known
+    std::function<void(size_t block, uint32_t info)> blockInfo;                 // per block: scanPosLast | CABAC_TU_INFO_*
   };
   // BinEncoderBase::getNumWrittenBits() (arith_codec.cpp:482-485) of an encoder that has coded `records` since
   // reset(qp, initId) and flushed nothing yet: one launch with CABAC_SUB_PROBE (cabac_hip.h).  For the recording encoders'
@@ -241,6 +256,10 @@ private:
   // that with pinned mirrors the page-locking is paid once
   RecordVector m_stageRecords;
   ByteVector m_stageBytes;
+  std::vector<int32_t, HostAllocator<int32_t>> m_stageCoeff;
+  size_t m_stagedBlocksOpen = 0;  // blocks staged by encoders that have not been flushed yet
+  void flushSpliced(std::vector<Pending> &done);
+  void deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits);
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -306,6 +325,15 @@ public:
   // is coded before flush(), and the call throws.  (The reference asks this only in estBits, cabac_writer.cpp:83-96.)
   unsigned getNumWrittenBits() override;
 
+  // CABACWriter::residual_coding's bins (cabac_writer.cpp:2424-2525) without binarising on the host: the block's
+  // coefficients are staged for the device and a splice marks the place of its bins among the recorded ones; flush() has
+  // them binarised, spliced in and coded on the device (cabac_hip_encode_batch_residual).  Code the block's
+  // transform_skip_flag, if it has one, with encodeBin before this call (b.tsFlag must be false).  The block's bins enter
+  // getNumBins() / getNumBins(ctxId) when they are known, at flush() — this encoder must still exist then.
+  // Throws for an all-zero block at flush() ("Coefficient coding called for empty TU", cabac_writer.cpp:2458).
+  void encodeResidual(const HipBatch::ResidualBlock &b);
+  size_t splicedBlocks() const { return m_blocks.size(); }
+
   const RecordVector &records() const { return m_records; }
 
 private:
@@ -314,8 +342,13 @@ private:
   Mode m_mode;
   OutputBitstream *m_Bitstream = nullptr;
   RecordVector m_records;
+  std::vector<cabac_splice> m_splices;
+  std::vector<cabac_tu_desc> m_blocks;
   int m_qp = 0, m_initId = 0;
 };
+
+// a ResidualBlock's geometry and flags as the C ABI wants them (throws for sizes that are not powers of two up to 64)
+cabac_tu_desc makeTuDesc(const HipBatch::ResidualBlock &b, uint64_t coeff_offset);
 
 // Recording bit estimator with the interface of the reference's BitEstimator_Std (arith_codec.hpp:159-213).
 // The calls since reset(qp, initId) are kept as bin records (resetBits() / start() / restart() as pseudo-records,

@@ -295,6 +295,54 @@ int cabac_hip_residual_device(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_
                               const uint64_t *d_rec_offset, uint32_t *d_n_records, uint32_t *d_info,
                               uint16_t *d_records);
 
+/* ---- coefficients -> bytes: residual records spliced into the substreams on the device (row f2, the writer's side) ----
+ * In the reference the bins of CABACWriter::residual_coding go straight into the bin encoder, in between the bins of the
+ * syntax elements around them (cabac_writer.cpp:2424-2525; flags :2766-2803, escapes :2822 / :2843, signs :2871).  Here the
+ * caller records the syntax elements it walks itself as bin records (desc[s].rec_offset / n_records, as for
+ * cabac_hip_encode_batch) and, for each transform block, a SPLICE: the block's records — exactly those
+ * cabac_hip_residual_device produces for tus[tu] — are inserted in front of host record `at` of the substream (at ==
+ * n_records: behind the last one; several blocks at the same `at` keep their list order).  Substream s owns
+ * splices[splice_first[s] .. splice_first[s + 1]), sorted by `at`; every block of tus[] is spliced exactly once.  The
+ * block records exist on the device only: sizes pass -> prefix sums -> records pass straight into the expanded substream ->
+ * encode kernel; bytes (and counts) are all that comes back.  Code the transform_skip_flag of a block (ts_flag,
+ * cabac_writer.cpp:2527-2534) as an ordinary host record in front of its splice and leave CABAC_TU_TS_FLAG clear.
+ * byte_offset / byte_capacity of the descriptors are ignored: the library sizes the byte slots itself (the expanded
+ * lengths are only known on the device).                                                                           */
+typedef struct cabac_splice {
+  uint32_t at; /* 0 .. desc[s].n_records */
+  uint32_t tu; /* index into tus[]        */
+} cabac_splice;
+
+/* bin_counts (optional): per substream CABAC_BIN_COUNT_WORDS words — the BinCounter totals of everything the substream
+ * codes, host records and spliced blocks alike (arith_codec.cpp:281-316): [ctxId] context-coded bins per context,
+ * [CABAC_NUM_CONTEXTS] bypass bins, [CABAC_NUM_CONTEXTS + 1] terminate bins.                                        */
+#define CABAC_BIN_COUNT_WORDS (CABAC_NUM_CONTEXTS + 2)
+
+/* Device-pointer form.  All inputs and outputs are device memory; intermediate buffers (block sizes, expanded records, byte
+ * slots) belong to the ctx and grow on demand.  The coded substreams arrive compacted, in descriptor order, in
+ * d_payload[d_payload_offsets[s] .. d_payload_offsets[s + 1]) (n_sub + 1 offsets) — byte-aligned when coded with
+ * CABAC_SUB_ALIGN_RBSP, i.e. what OutputBitstream::addSubstream makes of them (bit_stream.cpp:139-150).  d_tu_info (may be
+ * NULL): one word per block as cabac_hip_residual_device reports it; d_bin_counts (may be NULL) as above.
+ * Unlike the other *_device calls this one waits for the ctx's stream once in the middle (the expanded sizes decide the
+ * buffers and launch geometry of the second half); the rest is queued on the stream when it returns.
+ * Returns CABAC_HIP_ERR_INVALID for a splice list that is not sorted, points outside its substream or does not name
+ * every block exactly once (nothing is coded then).                                                                 */
+int cabac_hip_encode_residual_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                     const uint16_t *d_records, const uint32_t *d_splice_first, const cabac_splice *d_splices,
+                                     uint32_t n_splice, uint32_t n_tu, const cabac_tu_desc *d_tu, const int32_t *d_coeff,
+                                     uint8_t *d_payload, uint64_t payload_capacity, uint64_t *d_payload_offsets,
+                                     cabac_substream_result *d_results, uint32_t *d_tu_info, uint32_t *d_bin_counts);
+
+/* Host-pointer form (synchronous): pinned caller memory is DMA'd where it lies, pageable memory goes through the bounce ring.
+ * payload / payload_offsets / results / tu_info / bin_counts as above, in host memory.  Returns CABAC_HIP_ERR_SUBSTREAM if a
+ * result flag is set or a block is empty / has a bad descriptor (tu_info says which; its splice adds no records).     */
+int cabac_hip_encode_batch_residual(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                                    const uint16_t *records, uint64_t n_records_total, const uint32_t *splice_first,
+                                    const cabac_splice *splices, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                                    uint64_t n_coeff_total, uint8_t *payload, uint64_t payload_capacity,
+                                    uint64_t *payload_offsets, cabac_substream_result *results, uint32_t *tu_info,
+                                    uint32_t *bin_counts);
+
 /* ---- substream assembly on the device --------------
  * assemble: concatenate the coded substreams in descriptor order into d_payload — the effect of
  * OutputBitstream::addSubstream (bit_stream.cpp:139-150) on byte-aligned substreams (encode them with
@@ -399,7 +447,8 @@ int cabac_hip_residual_batch(cabac_hip_ctx *ctx, uint32_t n_tu, const cabac_tu_d
  * cabac_hip_profile_enable(ctx, capacity): from now on every device call (encode, decode, binarize, ...) is
  * bracketed by its own pair of HIP events on the stream it is launched on (up to `capacity` calls;
  * 0 disables and frees).  cabac_hip_profile_read synchronises the stream, writes kind[i]
- * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual, 6 assemble, 7 split, 8 count_emulations, 9 residual_parse) and ms[i] for the recorded calls in launch order,
+ * (0 encode, 1 decode, 2 binarize, 3 ctx_init, 4 estimate, 5 residual, 6 assemble, 7 split, 8 count_emulations, 9 residual_parse,
+ * 10 splice plan / scan / expand, 11 bin counts) and ms[i] for the recorded calls in launch order,
  * returns their number and resets the ring.                                 */
 int cabac_hip_profile_enable(cabac_hip_ctx *ctx, uint32_t capacity);
 int cabac_hip_profile_read(cabac_hip_ctx *ctx, int32_t *kind, float *ms, uint32_t max_entries);

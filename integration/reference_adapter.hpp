@@ -43,7 +43,10 @@ public:
   void uninit() override { m_Bitstream = nullptr; }
   void start() override {
     m_records.clear();
+    m_splices.clear();
+    m_blocks.clear();
     EntropyCoding::BinCounter::reset();
+    std::fill(m_devCtx.begin(), m_devCtx.end(), 0u);
   }
   void finish() override {
     HIPREF_CHECK(!m_Bitstream, "finish() without a bitstream");
@@ -59,8 +62,45 @@ public:
       for (uint32_t i = 0; i < whole; i++) bs->write(bytes[i], 8);  // same calls writeOut()/finish() make
       if (tail_bits) bs->write(uint32_t(bytes[whole]) >> (8 - tail_bits), tail_bits);
     };
+    if (!m_blocks.empty()) {  // residual blocks to be spliced in on the device (spliceResidual)
+      p.splices.swap(m_splices);
+      p.blocks.swap(m_blocks);
+      p.hostCounts.assign(CABAC_BIN_COUNT_WORDS, 0u);
+      for (unsigned k = 0; k < CABAC_NUM_CONTEXTS; k++) p.hostCounts[k] = EntropyCoding::BinCounter::getCtx(k);
+      p.hostCounts[CABAC_NUM_CONTEXTS] = uint32_t(p.nEp);
+      p.hostCounts[CABAC_NUM_CONTEXTS + 1] = uint32_t(p.nTrm);
+      BinEncoderHipRef *self = this;  // must outlive the flush (as the bitstream must)
+      p.counted = [self](const uint32_t *counts, const uint32_t *host) {
+        // the blocks' bins, known now: the reference's BinCounter keeps its per-context array private, so the context bins are
+        // kept here and added in getNumBins() / getNumBins(ctxId); the bypass bins go into the base class
+        for (unsigned k = 0; k < CABAC_NUM_CONTEXTS; k++) self->m_devCtx[k] += counts[k] - host[k];
+        self->EntropyCoding::BinCounter::addEP(counts[CABAC_NUM_CONTEXTS] - host[CABAC_NUM_CONTEXTS]);
+      };
+      std::vector<std::function<void(uint32_t)>> cbs;
+      cbs.swap(m_blockInfo);
+      p.blockInfo = [cbs](size_t k, uint32_t info) {
+        if (k < cbs.size() && cbs[k]) cbs[k](info);
+      };
+    }
     m_batch.submit(std::move(p));
     if (m_mode == Immediate) m_batch.flush();
+  }
+  // The bins CABACWriter::residual_coding would put into this encoder for block `b` (cabac_writer.cpp:2424-2525), without
+  // binarising on the host: the coefficients are staged for the device and a splice marks the place of the block's bins
+  // among the recorded ones (ResidualCoderHipRef does this for a TransformUnit).  onInfo (optional) receives the block's
+  // scanPosLast | CABAC_TU_INFO_* at flush().
+  void spliceResidual(const HipBatch::ResidualBlock &b, std::function<void(uint32_t)> onInfo = nullptr) {
+    HIPREF_CHECK(!b.coeff || b.tsFlag, "spliceResidual: code transform_skip_flag with encodeBin first; coefficients required");
+    cabac_tu_desc t;
+    try {
+      t = makeTuDesc(b, 0);
+    } catch (const EntropyCodingAMD::Exception &e) {
+      HIPREF_THROW(e.what());
+    }
+    t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height);
+    m_splices.push_back(cabac_splice{uint32_t(m_records.size()), uint32_t(m_blocks.size())});
+    m_blocks.push_back(t);
+    m_blockInfo.push_back(std::move(onInfo));
   }
   void restart() override { HIPREF_CHECK(!m_records.empty(), "restart() on a non-empty recording"); }
   void reset(int qp, int initId) override {
@@ -74,7 +114,8 @@ public:
     EntropyCoding::BinCounter::reset();
   }
   uint64_t getEstFracBits() const override { HIPREF_THROW("not supported"); }
-  unsigned getNumBins(unsigned ctxId) const override { return EntropyCoding::BinCounter::getCtx(ctxId); }
+  // (the bins of spliced residual blocks are in these numbers from the flush() that codes them on)
+  unsigned getNumBins(unsigned ctxId) const override { return EntropyCoding::BinCounter::getCtx(ctxId) + m_devCtx[ctxId]; }
 
   void encodeBin(unsigned bin, unsigned ctxId) override {
     HIPREF_CHECK(ctxId >= CABAC_NUM_CONTEXTS, "ctxId out of range");
@@ -103,10 +144,15 @@ public:
     put(CABAC_REC_TRM, bin);
   }
   void align() override { put(CABAC_REC_ALIGN, 0); }
-  uint32_t getNumBins() override { return EntropyCoding::BinCounter::getAll(); }
+  uint32_t getNumBins() override {
+    uint32_t n = EntropyCoding::BinCounter::getAll();
+    for (uint32_t c : m_devCtx) n += c;
+    return n;
+  }
   bool isEncoding() override { return true; }
   unsigned getNumWrittenBits() override {  // arith_codec.cpp:482-485; Immediate mode: one probing launch (HipBatch::numWrittenBits)
     HIPREF_CHECK(m_mode != Immediate, "getNumWrittenBits: nothing is coded before HipBatch::flush() in Deferred mode");
+    HIPREF_CHECK(!m_blocks.empty(), "getNumWrittenBits: the bins of spliced residual blocks are not known before flush()");
     HIPREF_CHECK(!m_Bitstream, "getNumWrittenBits() without a bitstream");
     try {
       return m_Bitstream->getNumberOfWrittenBits() + m_batch.numWrittenBits(m_records.data(), m_records.size(), m_qp, m_initId);
@@ -129,6 +175,10 @@ private:
   Mode m_mode;
   Common::OutputBitstream *m_Bitstream = nullptr;
   EntropyCodingAMD::RecordVector m_records;  // page-locked when EntropyCodingAMD::usePinnedMirrors(true) is set
+  std::vector<cabac_splice> m_splices;
+  std::vector<cabac_tu_desc> m_blocks;
+  std::vector<std::function<void(uint32_t)>> m_blockInfo;
+  std::vector<uint32_t> m_devCtx = std::vector<uint32_t>(CABAC_NUM_CONTEXTS, 0u);
   int m_qp = 0, m_initId = 0;
 };
 
@@ -182,9 +232,17 @@ private:
 // syntax walk runs, one launch for all of them, each block's bins handed to the encoder in order.
 // Covered: regular and transform-skip residual coding (with BDPCM).  Not covered (throws): the SBT/MTS zero-out of
 // last_sig_coeff and the range extensions (Rice extension, persistent Rice adaptation, TSRC Rice).
+//
+// Two forms.  On a BinEncoderHipRef (second constructor) a block costs the host one copy of its coefficients and one
+// pass over them for the CUCtx side effects: ts_flag is recorded as an ordinary bin, the coefficients are staged, a splice
+// marks the place of the block's bins, and HipBatch::flush() has them binarised, spliced into the substream and coded on
+// the device — the bins go "straight into the encoder" as in the reference (:2766-2803, :2822, :2843, :2871) and never
+// exist on the host.  On any other BinEncIf (first constructor; e.g. the reference's BinEncoder_Std, for checking) the
+// block records come back from the device and are replayed into the encoder call by call.
 class ResidualCoderHipRef {
 public:
   ResidualCoderHipRef(HipBatch &batch, EntropyCoding::BinEncIf &enc) : m_batch(batch), m_enc(enc) {}
+  ResidualCoderHipRef(HipBatch &batch, BinEncoderHipRef &enc) : m_batch(batch), m_enc(enc), m_hip(&enc) {}
 
   void residual_coding(const Common::TransformUnit &tu, Common::ComponentID compID, Common::CUCtx *cuCtx) {
     queue(tu, compID, cuCtx);
@@ -216,11 +274,13 @@ public:
     it.depQuant = tu.cs->slice->getDepQuantEnabledFlag();
     it.signHiding = tu.cs->slice->getSignDataHidingEnabledFlag();
     it.maxLog2 = sps.getMaxLog2TrDynamicRange(toChannelType(compID));
+    if (m_hip) return splice(tu, compID, it);
     m_items.push_back(std::move(it));
   }
 
   void flush() {
     using namespace Common;
+    if (m_hip) return;  // spliced blocks are coded by HipBatch::flush() with their substream
     std::vector<HipBatch::ResidualBlock> blocks;
     for (const Item &it : m_items) {
       HipBatch::ResidualBlock b;
@@ -275,8 +335,65 @@ private:
     int maxLog2 = 15;
     Common::CUCtx *cuCtx = nullptr;
   };
+
+  // the splice form of one block: ts_flag as a bin, the coefficients to the device, the CUCtx side effects at once
+  void splice(const Common::TransformUnit &tu, Common::ComponentID compID, const Item &it) {
+    using namespace Common;
+    if (it.tsAllowed) m_enc.encodeBin(it.tsFlag, Ctx::TransformSkipFlag(it.chroma ? 1 : 0));  // ts_flag, cabac_writer.cpp:2527-2534
+    // What the writer's walk leaves in the CUCtx depends on where the last significant coefficient lies and on which
+    // coefficient groups are significant (cabac_writer.cpp:2447-2477, :2519-2522).  A later syntax element may depend on it
+    // (lfnst_idx, mts_idx), so it cannot wait for the device: one pass over the coefficients in the reference's own scan
+    // order, with the reference's own CoeffCodingContext.  The device reports the same per block; flush() compares.
+    int last = -1;
+    bool violation = false;
+    if (!it.transformSkip) {
+      CoeffCodingContext cctx(tu, compID, it.signHiding);
+      const TCoeff *coeff = tu.getCoeffs(compID).buf;
+      int group = -1;
+      for (int scanPos = 0; scanPos < int(cctx.maxNumCoeff()); scanPos++) {
+        if (!coeff[cctx.blockPos(scanPos)]) continue;
+        last = scanPos;
+        const int sub = scanPos >> cctx.log2CGSize();
+        if (sub == group) continue;
+        group = sub;
+        cctx.initSubblock(sub, true);
+        violation = violation || (isLuma(compID) && (cctx.cgPosY() > 3 || cctx.cgPosX() > 3));
+      }
+      HIPREF_CHECK(last < 0, "Coefficient coding called for empty TU");  // cabac_writer.cpp:2458
+      if (CUCtx *cu = it.cuCtx) {
+        const ChannelType ch = it.chroma ? CHANNEL_TYPE_CHROMA : CHANNEL_TYPE_LUMA;
+        if (it.notSkip && it.height >= 4 && it.width >= 4) {
+          const int maxLfnstPos = ((it.height == 4 && it.width == 4) || (it.height == 8 && it.width == 8)) ? 7 : 15;
+          cu->violatesLfnstConstrained[ch] |= last > maxLfnstPos;
+          cu->lfnstLastScanPos |= last >= (it.chroma ? LFNST_LAST_SIG_CHROMA : LFNST_LAST_SIG_LUMA);
+        }
+        if (!it.chroma && it.notSkip) cu->mtsLastScanPos |= last >= 1;
+        if (!it.chroma && violation) cu->violatesMtsCoeffConstraint = true;
+      }
+    }
+    HipBatch::ResidualBlock b;
+    b.coeff = it.coeff.data();
+    b.width = it.width;
+    b.height = it.height;
+    b.chroma = it.chroma;
+    b.depQuant = it.depQuant;
+    b.signHiding = it.signHiding;
+    b.tsFlag = false;
+    b.transformSkip = it.transformSkip;
+    b.bdpcm = it.bdpcm;
+    b.maxLog2TrDynamicRange = it.maxLog2;
+    const bool regular = !it.transformSkip;
+    const bool luma = !it.chroma;
+    m_hip->spliceResidual(b, [last, violation, regular, luma](uint32_t info) {
+      if (!regular) return;
+      if (int(info & CABAC_TU_INFO_LAST_MASK) != last || (luma && bool(info & CABAC_TU_INFO_MTS_VIOLATION) != violation))
+        HIPREF_THROW("device and host disagree about a block's last significant position");
+    });
+  }
+
   HipBatch &m_batch;
   EntropyCoding::BinEncIf &m_enc;
+  BinEncoderHipRef *m_hip = nullptr;
   std::vector<Item> m_items;
 };
 

@@ -237,6 +237,59 @@ long adapter_residual(int which, int n, const int *wh, const int *comp, int rig_
   }
 }
 
+// The same blocks, each preceded by a few other syntax elements (ops[op_off[i] .. op_off[i + 1]) before block i, the rest after
+// the last one), coded (which = 0) by the reference's CABACWriter on BinEncoder_Std and (which = 1) by the reference's
+// CABACWriter on BinEncoderHipRef with ResidualCoderHipRef in its splice form: the coefficients go to the device, the block
+// bins never exist on the host, one HipBatch::flush() codes the substream.  cu[0..3] as adapter_residual, read BEFORE the
+// flush (a writer decides lfnst_idx / mts_idx from them while it walks); counts = {getNumBins(), getNumBins(ctx) for the
+// contexts listed in probe_ctx[0..7]} read after it.
+long adapter_residual_spliced(int which, int n, const int *wh, const int *comp, int rig_flags, const int32_t *coeff,
+                              const uint32_t *ops, const long *op_off, int qp, uint8_t *out, long cap, int32_t *cu,
+                              const int *probe_ctx, uint32_t *counts) {
+  try {
+    static ResidualRig rig;
+    EntropyCodingAMD::HipBatch batch(0);
+    BinEncoder_Std std_enc;
+    EntropyCodingAMD::BinEncoderHipRef hip_enc(batch);
+    BinEncIf &e = which == 0 ? static_cast<BinEncIf &>(std_enc) : static_cast<BinEncIf &>(hip_enc);
+    OutputBitstream bs;
+    CABACWriter w(e);
+    w.initBitstream(&bs);
+    e.reset(qp, 2);
+    EntropyCodingAMD::ResidualCoderHipRef hip(batch, hip_enc);
+    CUCtx cuCtx(0);
+    std::vector<std::unique_ptr<TransformUnit>> tus;
+    std::vector<std::vector<TCoeff>> bufs(n);
+    const int32_t *c = coeff;
+    for (int i = 0; i < n; i++) {
+      drive(w, e, ops + 4 * op_off[i], op_off[i + 1] - op_off[i]);
+      tus.emplace_back(new TransformUnit);
+      rig.make_tu(*tus[i], bufs[i], wh[2 * i], wh[2 * i + 1], comp[i], rig_flags, c);
+      c += wh[2 * i] * wh[2 * i + 1];
+      if (which == 0) w.residual_coding(*tus[i], ComponentID(comp[i]), &cuCtx);
+      else hip.queue(*tus[i], ComponentID(comp[i]), &cuCtx);
+    }
+    drive(w, e, ops + 4 * op_off[n], op_off[n + 1] - op_off[n]);
+    cu[0] = int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_LUMA]) | int(cuCtx.violatesLfnstConstrained[CHANNEL_TYPE_CHROMA]) << 1;
+    cu[1] = cuCtx.lfnstLastScanPos;
+    cu[2] = cuCtx.violatesMtsCoeffConstraint;
+    cu[3] = cuCtx.mtsLastScanPos;
+    e.encodeBinTrm(1);
+    e.finish();
+    batch.flush();
+    bs.writeByteAlignment();
+    counts[0] = e.getNumBins();
+    for (int k = 0; k < 8; k++) counts[1 + k] = static_cast<const BinEncIf &>(e).getNumBins(unsigned(probe_ctx[k]));
+    const std::vector<uint8_t> &f = bs.getFIFO();
+    if ((long)f.size() > cap) { strcpy(g_err, "capacity"); return -3; }
+    if (!f.empty()) memcpy(out, f.data(), f.size());
+    return (long)f.size();
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof(g_err) - 1);
+    return -1;
+  }
+}
+
 // ---- decoder side -----------------------------------------------------------------------------------------------------
 // n residual blocks of one substream, parsed (which = 0) by the reference's own CABACReader::residual_coding on
 // BinDecoder_Std, (which = 1) by ResidualParserHipRef on the device.  block_flags: rig flags per block

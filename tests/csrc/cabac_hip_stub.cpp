@@ -224,6 +224,85 @@ int cabac_hip_residual_batch(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_des
   return status;
 }
 
+// coefficients -> bytes: the splices resolved on the host with the oracle's block records
+int cabac_hip_encode_batch_residual(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                    uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
+                                    const cabac_tu_desc *tus, const int32_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                    uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
+                                    uint32_t *tu_info, uint32_t *bin_counts) {
+  if (!c || !payload_offsets || (n_sub && (!desc || !splice_first || !results || !payload)) || (n_tu && (!tus || !coeff || !splices)))
+    return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  payload_offsets[0] = 0;
+  if (n_sub == 0) return CABAC_HIP_OK;
+  if (splice_first[0] != 0 || splice_first[n_sub] != n_tu) return fail(c, CABAC_HIP_ERR_INVALID, "every block must be spliced exactly once");
+  std::vector<uint16_t> rec(records, records + n_records_total);  // exactly the declared sizes
+  std::vector<int32_t> co(coeff, coeff + n_coeff_total);
+  std::vector<cabac_splice> sp(splices, splices + n_tu);
+  std::vector<uint8_t> seen(n_tu ? n_tu : 1, 0);
+  std::vector<uint32_t> info(n_tu ? n_tu : 1, 0);
+  int status = CABAC_HIP_OK;
+  uint64_t at_payload = 0;
+  for (uint32_t s = 0; s < n_sub; s++) {
+    const cabac_substream_desc &d = desc[s];
+    if (d.rec_offset > n_records_total || d.n_records > n_records_total - d.rec_offset) return fail(c, CABAC_HIP_ERR_INVALID, "records out of range");
+    if (splice_first[s] > splice_first[s + 1]) return fail(c, CABAC_HIP_ERR_INVALID, "splice_first must not decrease");
+    std::vector<uint16_t> full;
+    uint32_t prev = 0;
+    for (uint32_t j = splice_first[s]; j < splice_first[s + 1]; j++) {
+      if (sp[j].tu >= n_tu || sp[j].at > d.n_records || sp[j].at < prev || seen[sp[j].tu]++)
+        return fail(c, CABAC_HIP_ERR_INVALID, "splice list: not sorted, outside its substream, or a block not spliced exactly once");
+      full.insert(full.end(), rec.begin() + d.rec_offset + prev, rec.begin() + d.rec_offset + sp[j].at);
+      prev = sp[j].at;
+      const cabac_tu_desc &t = tus[sp[j].tu];
+      if (t.log2_width > 6 || t.log2_height > 6 || t.channel > 1) {
+        info[sp[j].tu] = CABAC_TU_INFO_BAD_DESC;
+        status = CABAC_HIP_ERR_SUBSTREAM;
+        continue;
+      }
+      const uint64_t n = uint64_t(1) << (t.log2_width + t.log2_height);
+      if (t.coeff_offset > n_coeff_total || n > n_coeff_total - t.coeff_offset) return fail(c, CABAC_HIP_ERR_INVALID, "coefficients out of range");
+      const unsigned lw = t.log2_width < 5 ? t.log2_width : 5, lh = t.log2_height < 5 ? t.log2_height : 5;
+      std::vector<uint16_t> blk(CABAC_TU_MAX_RECORDS(1u << (lw + lh)));
+      const long k = orc_residual_records(t.log2_width, t.log2_height, t.channel, t.flags, t.max_log2_tr_range, co.data() + t.coeff_offset,
+                                          blk.data(), (long)blk.size(), &info[sp[j].tu]);
+      if (k < 0) {
+        info[sp[j].tu] = k == -1 ? CABAC_TU_INFO_EMPTY : CABAC_TU_INFO_BAD_DESC;
+        status = CABAC_HIP_ERR_SUBSTREAM;
+        continue;
+      }
+      full.insert(full.end(), blk.begin(), blk.begin() + k);
+    }
+    full.insert(full.end(), rec.begin() + d.rec_offset + prev, rec.begin() + d.rec_offset + d.n_records);
+    std::vector<uint8_t> out(cabac_hip_encode_bound(full.size(), full.size(), full.size()) + 1);
+    uint32_t nbits = 0;
+    const int fl = ((d.init_id & CABAC_SUB_FINISH) ? 1 : 0) | ((d.init_id & CABAC_SUB_ALIGN_RBSP) ? 2 : 0);
+    const long nb = orc_encode_records(full.data(), (long)full.size(), d.qp, int(d.init_id & 3u), fl, out.data(), (long)out.size() - 1, &nbits);
+    results[s].n_bits = nbits;
+    results[s].flags = nb == -2 ? CABAC_RES_BAD_RECORD : nb == -3 ? CABAC_RES_OVERFLOW : 0;
+    if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
+    const uint64_t nbytes = nb > 0 ? uint64_t(nb) : 0;
+    if (at_payload + nbytes > payload_capacity) return fail(c, CABAC_HIP_ERR_INVALID, "payload_capacity too small");
+    if (nbytes) std::memcpy(payload + at_payload, out.data(), nbytes);
+    at_payload += nbytes;
+    payload_offsets[s + 1] = at_payload;
+    if (bin_counts) {
+      uint32_t *cnt = bin_counts + size_t(s) * CABAC_BIN_COUNT_WORDS;
+      std::memset(cnt, 0, CABAC_BIN_COUNT_WORDS * sizeof(uint32_t));
+      for (uint16_t r : full) {
+        const unsigned id = r & CABAC_REC_ID_MASK;
+        if (id < CABAC_NUM_CONTEXTS) cnt[id]++;
+        else if (id == CABAC_REC_EP) cnt[CABAC_NUM_CONTEXTS]++;
+        else if (id == CABAC_REC_TRM) cnt[CABAC_NUM_CONTEXTS + 1]++;
+      }
+    }
+  }
+  for (uint32_t t = 0; t < n_tu; t++)
+    if (!seen[t]) return fail(c, CABAC_HIP_ERR_INVALID, "splice list: not sorted, outside its substream, or a block not spliced exactly once");
+  if (tu_info && n_tu) std::memcpy(tu_info, info.data(), n_tu * sizeof(uint32_t));
+  if (status) c->last_error = "substream flag set, or an empty / badly described block (see results[].flags, tu_info[])";
+  return status;
+}
+
 int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
                                    uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
                                    uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {

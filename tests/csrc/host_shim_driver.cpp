@@ -136,6 +136,64 @@ long shim_num_written_bits(const uint32_t *ops, long n_ops, int qp, int init_id,
   }
 }
 
+// GPU: n_streams substreams of host-recorded ops with residual blocks spliced in (BinEncoderHip::encodeResidual): substream s
+// applies its ops in order and, before op number blk_at[b] (== its op count: at the end), splices block b of its blocks
+// blk_first[s] .. blk_first[s + 1]; geom[4b..] = {width, height, chroma, CABAC_TU_* flags}, coefficients back to back.
+// One flush for all.  out / n_bits as shim_encode_streams; counts[s * 4 ..] = {ctx, EP, TRM, getNumBins()} after the flush.
+int shim_spliced_streams(int n_streams, const uint32_t *ops, const long *op_off, const int *blk_first, const int *blk_at,
+                         const int *geom, const int32_t *coeff, const int *qp, const int *init_id, int mode, uint8_t *out,
+                         const long *out_off, uint32_t *n_bits, uint32_t *counts) {
+  try {
+    HipBatch batch(0);
+    std::vector<std::unique_ptr<BinEncoderHip>> enc;
+    std::vector<OutputBitstream> bs(n_streams);
+    const int32_t *cin = coeff;
+    for (int s = 0; s < n_streams; s++) {
+      enc.emplace_back(new BinEncoderHip(batch, mode ? BinEncoderHip::Immediate : BinEncoderHip::Deferred));
+      BinEncoderHip &e = *enc.back();
+      e.init(&bs[s]);
+      e.reset(qp[s], init_id[s]);
+      const long n_ops = op_off[s + 1] - op_off[s];
+      int b = blk_first[s];
+      for (long i = 0; i <= n_ops; i++) {
+        for (; b < blk_first[s + 1] && blk_at[b] == i; b++) {
+          HipBatch::ResidualBlock r{};
+          r.coeff = cin;
+          r.width = unsigned(geom[4 * b]);
+          r.height = unsigned(geom[4 * b + 1]);
+          r.chroma = geom[4 * b + 2] != 0;
+          r.depQuant = (geom[4 * b + 3] & CABAC_TU_DEP_QUANT) != 0;
+          r.signHiding = (geom[4 * b + 3] & CABAC_TU_SIGN_HIDING) != 0;
+          r.transformSkip = (geom[4 * b + 3] & CABAC_TU_TRANSFORM_SKIP) != 0;
+          r.bdpcm = (geom[4 * b + 3] & CABAC_TU_BDPCM) != 0;
+          e.encodeResidual(r);
+          cin += r.width * r.height;
+        }
+        if (i < n_ops) apply_ops(e, ops + 4 * (op_off[s] + i), 1);
+      }
+      e.encodeBinTrm(1);
+      e.finish();
+    }
+    batch.flush();
+    for (int s = 0; s < n_streams; s++) {
+      bs[s].writeByteAlignment();
+      n_bits[s] = bs[s].getNumberOfWrittenBits();
+      const long cap = out_off[s + 1] - out_off[s];
+      if ((long)bs[s].m_fifo.size() > cap) return -3;
+      if (!bs[s].m_fifo.empty()) memcpy(out + out_off[s], bs[s].m_fifo.data(), bs[s].m_fifo.size());
+      BinEncoderHip &e = *enc[s];
+      counts[4 * s + 1] = e.getEP();
+      counts[4 * s + 2] = e.getTrm();
+      counts[4 * s + 3] = static_cast<BinEncIf &>(e).getNumBins();
+      counts[4 * s] = counts[4 * s + 3] - counts[4 * s + 1] - counts[4 * s + 2];
+    }
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 // GPU: replay-decode one substream: plan the record ids, run, then pull every bin back through the
 // BinDecoderBase-shaped calls.  Returns 0, or -1 with shim_last_error() (e.g. "FIFO exceeded").
 int shim_decode_replay(const uint16_t *rec, long n, int qp, int init_id, const uint8_t *bytes, long n_bytes,

@@ -339,6 +339,58 @@ def test_shim_get_num_written_bits_immediate_mode(drv):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shim_spliced_residual_blocks(drv, mode):
+    """BinEncoderHip::encodeResidual: coefficients handed over where the reference's writer would call residual_coding
+    (cabac_writer.cpp:2424-2525), their bins spliced in between the recorded ones on the device at flush().  Bytes and
+    BinCounter totals against the oracle coding the same substreams from host-side records."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(170 + mode)
+    n = 9
+    op_list, blk_first, blk_at, geom, coeffs, want, want_counts = [], [0], [], [], [], [], []
+    qps, ids = rng.integers(0, 64, size=n), rng.integers(0, 3, size=n)
+    for s in range(n):
+        ops = H.random_ops(rng, int(rng.integers(0, 60)), ctx_frac=0.6, end_trm=False)
+        ats = np.sort(rng.integers(0, len(ops) + 1, size=0 if s == 4 else int(rng.integers(1, 9))))
+        parts, prev = [], 0
+        for at in ats:
+            w, h = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (2, 8), (64, 64)][int(rng.integers(0, 7))]
+            ts = w <= 32 and rng.random() < 0.3
+            fl = (int(rng.integers(0, 2)) | H.TU_TRANSFORM_SKIP) if ts else int(rng.integers(0, 4))
+            c = H.random_block(rng, w, h, density=0.5, big=0.1)
+            ch = int(rng.integers(0, 2))
+            geom.append((w, h, ch, fl)); coeffs.append(c.ravel()); blk_at.append(int(at))
+            parts.append(orc.ops_to_records(ops[prev:int(at)]) if at > prev else np.zeros(0, np.uint16))
+            parts.append(orc.residual_records(c, ch, fl)[0])
+            prev = int(at)
+        parts.append(orc.ops_to_records(ops[prev:]) if len(ops) > prev else np.zeros(0, np.uint16))
+        parts.append(np.array([0x81FF], np.uint16))
+        rec = np.concatenate(parts)
+        want.append(orc.encode_records(rec, int(qps[s]), int(ids[s]), 3))
+        idv = rec & 0x1FF
+        want_counts.append((int((idv < H.NUM_CTX).sum()), int((idv == H.REC_EP).sum()), int((idv == H.REC_TRM).sum())))
+        op_list.append(ops); blk_first.append(len(geom))
+    ops = np.concatenate(op_list).astype(np.uint32) if sum(len(o) for o in op_list) else np.zeros((1, 4), np.uint32)
+    op_off = np.concatenate([[0], np.cumsum([len(o) for o in op_list])]).astype(np.int64)
+    out_off = np.concatenate([[0], np.cumsum([len(w[0]) + 64 for w in want])]).astype(np.int64)
+    out = np.zeros(int(out_off[-1]), np.uint8)
+    nbits = np.zeros(n, np.uint32)
+    counts = np.zeros(4 * n, np.uint32)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    drv.shim_spliced_streams.argtypes = [ctypes.c_int, u32p, lp, ip, ip, ip, i32p, ip, ip, ctypes.c_int, u8p, lp, u32p, u32p]
+    rc = drv.shim_spliced_streams(n, H._ptr(ops, u32p), op_off.ctypes.data_as(lp), np.array(blk_first, np.int32).ctypes.data_as(ip),
+                                  np.array(blk_at + [0], np.int32).ctypes.data_as(ip), np.array(geom, np.int32).ravel().ctypes.data_as(ip),
+                                  np.concatenate(coeffs).astype(np.int32).ctypes.data_as(i32p), np.asarray(qps, np.int32).ctypes.data_as(ip),
+                                  np.asarray(ids, np.int32).ctypes.data_as(ip), mode, H._ptr(out, u8p), out_off.ctypes.data_as(lp),
+                                  H._ptr(nbits, u32p), H._ptr(counts, u32p))
+    assert rc == 0, drv.shim_last_error()
+    for s in range(n):
+        wb, wbits = want[s]
+        assert int(nbits[s]) == wbits and np.array_equal(out[int(out_off[s]): int(out_off[s]) + len(wb)], wb), s
+        assert tuple(int(x) for x in counts[4 * s: 4 * s + 3]) == want_counts[s] and int(counts[4 * s + 3]) == sum(want_counts[s]), s
+
+
+@pytest.mark.gpu
 def test_shim_decode_replay(drv):
     orc = H.load_oracle()
     rng = np.random.default_rng(91)

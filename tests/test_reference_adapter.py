@@ -173,6 +173,55 @@ def test_transform_skip_residual_through_the_gpu_binariser_matches_reference_wri
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rig_flags", [0, 3, 7, 0x14, 0x30])
+def test_residual_blocks_spliced_on_the_device_match_reference_writer(adp, rig_flags):
+    """Row f2 closed end to end: the reference's CABACWriter on BinEncoderHipRef, residual_coding replaced by
+    ResidualCoderHipRef's splice form — coefficients to the device, the block bins spliced into the recorded ones there, one
+    flush — against the reference's CABACWriter::residual_coding on BinEncoder_Std with other syntax elements in between:
+    same bytes, same CUCtx (read before the flush), same getNumBins() / getNumBins(ctxId) (after it)."""
+    rng = np.random.default_rng(0xF2 + rig_flags)
+    ts = bool(rig_flags & 0x10)
+    sizes = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (4, 16), (2, 8)] + ([] if ts else [(64, 64), (64, 16)])
+    blocks, comps, op_list = [], [], []
+    for k in range(24):
+        w, h = sizes[k % len(sizes)]
+        if ts:
+            c = ((rng.random((h, w)) < 0.5) * rng.integers(-20, 21, (h, w))).astype(np.int32)
+            if not c.any():
+                c[0, 0] = 1
+        else:
+            c = H.random_block(rng, w, h, density=[0.1, 0.4, 0.9][k % 3], big=[0.0, 0.1, 0.3][k % 3], last_frac=[1.0, 0.4][k % 2])
+        blocks.append(c)
+        comps.append(int(rng.integers(0, 3)))
+        op_list.append(H.random_ops(rng, int(rng.integers(0, 6)), ctx_frac=0.7, end_trm=False))
+    op_list.append(H.random_ops(rng, 5, ctx_frac=0.7, end_trm=False))
+    wh = np.array([[c.shape[1], c.shape[0]] for c in blocks], np.int32).ravel()
+    comp = np.array(comps, np.int32)
+    coeff = np.concatenate([c.ravel() for c in blocks]).astype(np.int32)
+    ops = np.concatenate(op_list).astype(np.uint32)
+    op_off = np.concatenate([[0], np.cumsum([len(o) for o in op_list])]).astype(np.int64)
+    probe = np.array([90, 102, 150, 182, 246, 269, 310, 373], np.int32)
+    ip, lp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long)
+    f = adp.adapter_residual_spliced
+    f.restype = ctypes.c_long
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), H.u32p, lp, ctypes.c_int, H.u8p,
+                  ctypes.c_long, ctypes.POINTER(ctypes.c_int32), ip, H.u32p]
+    got = []
+    for which in (0, 1):
+        out = np.zeros(64 + 8 * len(coeff), np.uint8)
+        cu = np.zeros(8, np.int32)
+        counts = np.zeros(9, np.uint32)
+        n = f(which, len(blocks), wh.ctypes.data_as(ip), comp.ctypes.data_as(ip), rig_flags, coeff.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+              H._ptr(ops, H.u32p), op_off.ctypes.data_as(lp), 30, H._ptr(out, H.u8p), len(out), cu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+              probe.ctypes.data_as(ip), H._ptr(counts, H.u32p))
+        assert n >= 0, adp.adapter_last_error()
+        got.append((out[:n].copy(), cu[:4].copy(), counts.copy()))
+    assert np.array_equal(got[1][0], got[0][0])
+    assert np.array_equal(got[1][1], got[0][1])
+    assert np.array_equal(got[1][2], got[0][2]) and got[0][2][0] > 100
+
+
+@pytest.mark.gpu
 def test_residual_adapter_empty_block_throws_like_the_reference(adp):
     z = [np.zeros((8, 8), np.int32)]
     for which in (0, 1):
