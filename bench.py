@@ -173,6 +173,35 @@ def cpu_baseline(cfg, desc, records, budget_s):
     }
 
 
+def whole_batch_hash(desc, records, res_e, host_bytes):
+    """Every substream of the batch, not a sample: a digest of the bytes the compiled reference (oracle/_ref, or the C
+    restatement where it is not built) produces for each substream against the same digest of the device's bytes.  After
+    the timed region; the checker's libraries are test infrastructure."""
+    import ctypes
+    import helpers as H
+    n = len(desc)
+    desc = np.ascontiguousarray(desc)
+    want = np.zeros(n, np.uint64)
+    if H.ref_available():
+        lib, fn, kind = H.load_ref().lib, "ref_digest_mt", "reference"
+    else:
+        lib, fn, kind = H.load_oracle().lib, "orc_digest_mt", "port"
+    run = getattr(lib, fn)
+    run.restype = ctypes.c_uint64
+    run.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    t0 = time.perf_counter()
+    bad = run(desc.ctypes.data, 0, n, records.ctypes.data, min(_usable_cores(), 32), want.ctypes.data)
+    got = np.zeros(n, np.uint64)
+    dig = H.load_oracle().lib.orc_digest_slots
+    dig.restype = None
+    dig.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    res = np.ascontiguousarray(res_e)
+    dig(desc.ctypes.data, res.ctypes.data, n, host_bytes.ctypes.data, got.ctypes.data)
+    differ = int((got != want).sum())
+    return {"substreams": n, "differ": differ + int(bad), "checker": kind, "seconds": round(time.perf_counter() - t0, 2),
+            "match": differ == 0 and int(bad) == 0}
+
+
 def co_scheduled_leg(local_rank, variants, n_sub, n_bins, n_slots, t_desc, t_rec, bytes_total, want_bins, steps, warmup):
     """The same step — one encode and one decode of the whole resident batch — with the two kernels on two streams: the
     decode of step k (reading what the encode of step k wrote, after its event) runs beside the encode of step k + 1
@@ -320,7 +349,7 @@ def n_coef_total(c_u, copies):
     return c_u * copies
 
 
-def residual_leg(hip, n_tiles, unique=256, reps=4):
+def residual_leg(hip, n_tiles, unique=256, reps=4, host_e2e=True):
     """Coefficient blocks -> bin records (cabac_hip_residual_device), both passes, on n_tiles tiles of
     workload.RESIDUAL_TILE_MIX (`unique` generated tiles, replicated on the device).  Checked against the md5 the
     compiled reference produced for the first blocks (tests/golden/residual_bench.json) and replica against replica."""
@@ -400,6 +429,68 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
                   and bool(torch.equal(t_bins, (t_rec < 0).to(torch.uint8))))
     ok = ok and round_trip
     out_bytes = int(((res["n_bits"].astype(np.int64) + 7) // 8).sum())
+    # ... the same in ONE call with the block records spliced into the substreams on the device (cabac_hip_encode_residual_device:
+    # sizes pass -> prefix sums -> records pass straight into the expanded substreams -> encode -> compaction): the host side
+    # of a tile is its terminate bin and 400 splices in front of it.  Wall time of the call (it waits once in the middle).
+    sp_desc = np.zeros(n_tiles, capi.DESC_DTYPE)
+    sp_desc["n_records"], sp_desc["rec_offset"], sp_desc["qp"] = 1, np.arange(n_tiles, dtype=np.uint64), 32
+    sp_desc["init_id"] = 2 | capi.SUB_FINISH | capi.SUB_ALIGN_RBSP
+    sp_first = (np.arange(n_tiles + 1, dtype=np.uint32) * per_tile).astype(np.uint32)
+    sp_list = np.zeros(n, capi.SPLICE_DTYPE)
+    sp_list["tu"] = np.arange(n, dtype=np.uint32)
+    sp_rec = np.full(n_tiles, 0x81FF, np.uint16)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    t_sp_desc, t_sp_first, t_sp_list, t_sp_rec = dev(sp_desc), dev(sp_first), dev(sp_list), dev(sp_rec)
+    t_pay = torch.zeros(out_bytes + 64, dtype=torch.uint8, device="cuda")
+    t_poff = torch.zeros(n_tiles + 1, dtype=torch.int64, device="cuda")
+    t_pres = torch.zeros(2 * n_tiles, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    t_sp = []
+    hip.profile_enable(0)
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        hip.encode_residual_device(n_tiles, t_sp_desc.data_ptr(), t_sp_rec.data_ptr(), t_sp_first.data_ptr(), t_sp_list.data_ptr(), n, n,
+                                   t_tu.data_ptr(), t_co.data_ptr(), t_pay.data_ptr(), out_bytes + 64, t_poff.data_ptr(), t_pres.data_ptr())
+        hip.synchronize()
+        t_sp.append(time.perf_counter() - t0)
+    hip.profile_enable(16)
+    hip.encode_residual_device(n_tiles, t_sp_desc.data_ptr(), t_sp_rec.data_ptr(), t_sp_first.data_ptr(), t_sp_list.data_ptr(), n, n,
+                               t_tu.data_ptr(), t_co.data_ptr(), t_pay.data_ptr(), out_bytes + 64, t_poff.data_ptr(), t_pres.data_ptr())
+    sp_prof = {}
+    for kk, ms in hip.profile_read():
+        sp_prof[kk] = sp_prof.get(kk, 0.0) + ms
+    nb_all = (res["n_bits"].astype(np.int64) + 7) // 8
+    pres = t_pres.cpu().numpy().view(capi.RESULT_DTYPE)
+    poff = t_poff.cpu().numpy()
+    spliced_ok = bool(np.array_equal(pres["n_bits"], res["n_bits"])) and not pres["flags"].any() and int(poff[-1]) == out_bytes
+    host_pay, host_slots = t_pay.cpu().numpy(), t_bytes.cpu().numpy()
+    for s in range(0, n_tiles, max(n_tiles // 512, 1)):
+        o = int(desc["byte_offset"][s])
+        spliced_ok = spliced_ok and bool(np.array_equal(host_pay[int(poff[s]): int(poff[s + 1])], host_slots[o:o + int(nb_all[s])]))
+    spliced = {"call_ms": round(min(t_sp[1:]) * 1e3, 4), "mcoeff_s": round(c_u * copies / min(t_sp[1:]) / 1e6, 1),
+               "mbins_s": round(n_bins / min(t_sp[1:]) / 1e6, 1),
+               "kernel_ms": {"residual_passes": round(sp_prof.get(5, 0.0), 4), "splice_plan_scan_expand": round(sp_prof.get(10, 0.0), 4),
+                             "encode": round(sp_prof.get(0, 0.0), 4), "assemble": round(sp_prof.get(6, 0.0), 4)},
+               "bytes_match_record_path": bool(spliced_ok),
+               "what": "cabac_hip_encode_residual_device: coefficients + 1 host record per tile -> compacted coded substreams, wall time"}
+    if host_e2e:
+        # ... and from pinned host memory (cabac_hip_encode_batch_residual): 4 bytes per coefficient go up, only bytes come back
+        keep = [capi.PinnedArray((c_u * copies,), np.int32), capi.PinnedArray((out_bytes + 64,), np.uint8)]
+        for r in range(copies):
+            keep[0].array[r * c_u:(r + 1) * c_u] = coeff
+        t_h = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            h_off, h_res = hip.encode_batch_residual(sp_desc, sp_rec, sp_first, sp_list, all_tus, keep[0].array, keep[1].array)
+            t_h.append(time.perf_counter() - t0)
+        e2e_ok = bool(np.array_equal(h_res["n_bits"], res["n_bits"])) and bool(np.array_equal(keep[1].array[:out_bytes], host_pay[:out_bytes]))
+        spliced["from_pinned_host"] = {"call_ms": round(min(t_h[1:]) * 1e3, 3), "mcoeff_s": round(c_u * copies / min(t_h[1:]) / 1e6, 1),
+                                       "mbins_s": round(n_bins / min(t_h[1:]) / 1e6, 1), "h2d_bytes": int(4 * c_u * copies + 24 * n + 38 * n_tiles),
+                                       "d2h_bytes": int(out_bytes + 16 * n_tiles), "bytes_match": e2e_ok}
+        spliced_ok = spliced_ok and e2e_ok
+        for kp in keep:
+            kp.close()
+    ok = ok and spliced_ok
     # ... and back: the residual parser turns the bytes into coefficient blocks again, deriving every context itself.
     # The workload codes with sign-data hiding and its hidden signs are arranged as an encoder's quantiser leaves them
     # (workload._arrange_hidden_signs), so every coefficient must come back exactly.
@@ -437,6 +528,7 @@ def residual_leg(hip, n_tiles, unique=256, reps=4):
                          "mbins_s": round(2 * n_bins / ((enc + dec) * 1e-3) / 1e6, 1),
                          "coefficients_to_bytes_ms": round(p1 + p2 + enc, 4),
                          "bitstream_bytes": out_bytes, "round_trip": bool(round_trip)},
+            "coefficients_to_bytes": spliced,
             # bytes -> coefficients by the residual parser (contexts derived on the device, nothing supplied but block sizes)
             "parse": {"kernel": "residual_parse_kernel", "kernel_ms": round(parse_ms, 4),
                       "mbins_s": round(n_bins / (parse_ms * 1e-3) / 1e6, 1), "mcoeff_s": round(n_coef / (parse_ms * 1e-3) / 1e6, 1),
@@ -593,6 +685,7 @@ def main():
     ok = ok and bool(torch.equal(t_bins[:n_slots], want_bins))
     out_bytes = int(((res_e["n_bits"].astype(np.int64) + 7) // 8).sum())
     hash_match = None
+    whole_hash = None
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_md5.json")))[cfg.name]
     if args.strong:
         # every rank compacts its coded substreams on the device; they travel back to rank 0 device to device and are put
@@ -633,6 +726,9 @@ def main():
             if s is not None:
                 o, nb = int(desc["byte_offset"][s]), (int(res_e["n_bits"][s]) + 7) // 8
                 hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
+        # ... and every substream of the batch against the checker's bytes (the golden md5s above cover a sample)
+        whole_hash = whole_batch_hash(desc, records, res_e, host_bytes)
+        hash_match = hash_match and whole_hash["match"]
         del host_bytes
 
     # ---- bit estimator on the same resident records, outside the timed region ----
@@ -677,7 +773,7 @@ def main():
     residual = None
     if world == 1 and cfg.name == "C4" and not args.no_residual and not args.strong:
         try:
-            residual = residual_leg(hip, n_sub)
+            residual = residual_leg(hip, n_sub, host_e2e=not args.no_end_to_end)
         except Exception as e:  # the headline line must not depend on this leg
             residual = {"error": "%s: %s" % (type(e).__name__, e), "records_match_reference": False}
 
@@ -742,6 +838,7 @@ def main():
             "kernel_ms": {"encode": round(enc_avg, 4), "decode": round(dec_avg, 4)},
             "bitstream_bytes_per_gpu": out_bytes,
             "hash_match": bool(hash_match and ok),
+            "hash_whole_batch": whole_hash,
             "roofline": {
                 "bound": "hbm",        # the roof the tier prices against; what limits these kernels is in `limiter`
                 "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD issues one instruction per ~2 ns: ~640 per 16-bin decode step); HBM traffic equals the algorithmic bytes",

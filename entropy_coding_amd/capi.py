@@ -40,7 +40,7 @@ EXPORTS = [
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
     "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload", "cabac_hip_wait_event", "cabac_hip_record_event",
-    "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual",
+    "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual", "cabac_hip_gather_records_device",
 ]
 
 _lib = None
@@ -107,6 +107,7 @@ def load_library():
                                                    vp, ctypes.c_uint64, vp, vp, vp, vp]
     L.cabac_hip_encode_batch_residual.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint32, vp, vp,
                                                   ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, vp]
+    L.cabac_hip_gather_records_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
     L.cabac_hip_last_kernel_ms.argtypes = [vp]
     L.cabac_hip_assemble_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint64, vp]
@@ -399,6 +400,9 @@ class CabacHip:
     def assemble_device(self, n_sub, d_desc, d_results, d_bytes, d_payload, payload_capacity, d_offsets):
         self._check(self.L.cabac_hip_assemble_device(self.h, n_sub, vp(d_desc), vp(d_results), vp(d_bytes), vp(d_payload),
                                                      payload_capacity, vp(d_offsets)))
+
+    def gather_records_device(self, n_seg, d_src_off, d_dst_off, d_len, d_src, d_dst):
+        self._check(self.L.cabac_hip_gather_records_device(self.h, n_seg, vp(d_src_off), vp(d_dst_off), vp(d_len), vp(d_src), vp(d_dst)))
 
     def split_device(self, n_sub, d_desc, d_offsets, d_payload, d_bytes):
         self._check(self.L.cabac_hip_split_device(self.h, n_sub, vp(d_desc), vp(d_offsets), vp(d_payload), vp(d_bytes)))

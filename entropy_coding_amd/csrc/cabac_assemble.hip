@@ -118,6 +118,34 @@ __global__ __launch_bounds__(256) void count_emulations_kernel(uint32_t n_sub, c
   if (lane == 0u) counts[s] = cnt;
 }
 
+// segments of bin records gathered into one buffer: segment k = src[src_off[k] .. + len[k]) -> dst[dst_off[k] ..) (offsets
+// in records).  What re-packing a batch's substreams into per-GPU shards needs (entropy_coding_amd/sharding.py).
+__global__ __launch_bounds__(256) void gather_records_kernel(uint32_t n_seg, const uint64_t *__restrict__ src_off,
+                                                             const uint64_t *__restrict__ dst_off, const uint32_t *__restrict__ len,
+                                                             const uint16_t *__restrict__ src, uint16_t *__restrict__ dst) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n_seg) return;
+  const uint16_t *s = src + src_off[k];
+  uint16_t *d = dst + dst_off[k];
+  const uint32_t n = len[k];
+  // dwords where source and destination are two-byte-misaligned alike, single records at the ends and otherwise
+  uint32_t head = (uint32_t)(((uintptr_t)d >> 1) & 1u);
+  if (((((uintptr_t)s) ^ ((uintptr_t)d)) & 2u) != 0 || n < 8u) head = n;
+  head = head < n ? head : n;
+  for (uint32_t i = threadIdx.x; i < head; i += 256u) d[i] = s[i];
+  const uint32_t pairs = (n - head) >> 1;
+  const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s + head);
+  uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
+  for (uint32_t i = threadIdx.x; i < pairs; i += 256u) d32[i] = s32[i];
+  if (threadIdx.x == 0 && ((n - head) & 1u)) d[n - 1] = s[n - 1];
+}
+
+hipError_t launch_gather_records(hipStream_t st, uint32_t n_seg, const uint64_t *src_off, const uint64_t *dst_off, const uint32_t *len,
+                                 const uint16_t *src, uint16_t *dst) {
+  if (n_seg) hipLaunchKernelGGL(gather_records_kernel, dim3(n_seg), dim3(256), 0, st, n_seg, src_off, dst_off, len, src, dst);
+  return hipGetLastError();
+}
+
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,
                            uint64_t payload_capacity, uint64_t *offsets) {

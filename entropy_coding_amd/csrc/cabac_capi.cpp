@@ -618,6 +618,15 @@ int cabac_hip_count_emulations_device(cabac_hip_ctx *c, uint32_t n_sub, const ca
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_gather_records_device(cabac_hip_ctx *c, uint32_t n_seg, const uint64_t *d_src_off, const uint64_t *d_dst_off,
+                                    const uint32_t *d_len, const uint16_t *d_src, uint16_t *d_dst) {
+  if (!c || (n_seg && (!d_src_off || !d_dst_off || !d_len || !d_src || !d_dst))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  DeviceGuard g(c->device);
+  HIP_TRY(c, cabac::launch_gather_records(c->stream, n_seg, d_src_off, d_dst_off, d_len, d_src, d_dst));
+  c->timed = false;
+  return CABAC_HIP_OK;
+}
+
 float cabac_hip_last_kernel_ms(cabac_hip_ctx *c) {
   if (!c || !c->timed) return -1.0f;
   DeviceGuard g(c->device);

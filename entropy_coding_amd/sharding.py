@@ -115,12 +115,35 @@ def pack_shard(desc, records, idxs):
     caps = sub["byte_capacity"].astype(np.int64)
     sub["rec_offset"] = np.concatenate([[0], np.cumsum(lens)[:-1]]) if len(idxs) else []
     sub["byte_offset"] = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16)[:-1]]) if len(idxs) else []
+    if isinstance(records, torch.Tensor) and records.is_cuda and len(idxs):
+        # one gather launch on the device (cabac_hip_gather_records_device) instead of one slice per substream and a cat
+        total = int(lens.sum())
+        recs = torch.empty(total, dtype=records.dtype, device=records.device)
+        dev = records.device
+        src = torch.from_numpy(desc["rec_offset"][idxs].astype(np.int64)).to(dev)
+        dst = torch.from_numpy(sub["rec_offset"].astype(np.int64)).to(dev)
+        ln = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        hip = _gather_ctx(dev.index if dev.index is not None else torch.cuda.current_device())
+        hip.gather_records_device(len(idxs), src.data_ptr(), dst.data_ptr(), ln.data_ptr(), records.data_ptr(), recs.data_ptr())
+        return sub, recs, int(((caps + 15) // 16 * 16).sum())
     pieces = [records[int(desc["rec_offset"][i]):int(desc["rec_offset"][i]) + int(desc["n_records"][i])] for i in idxs]
     if isinstance(records, torch.Tensor):
         recs = torch.cat(pieces) if pieces else records[:0]
     else:
         recs = np.concatenate(pieces) if pieces else np.zeros(0, np.uint16)
     return sub, recs, int(((caps + 15) // 16 * 16).sum())
+
+
+_gather = {}
+
+
+def _gather_ctx(device):
+    """A codec context on torch's current stream of `device` for the gather launches (kept: one per device)."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    key = (device, stream)
+    if key not in _gather:
+        _gather[key] = capi.CabacHip(device, stream=stream)
+    return _gather[key]
 
 
 def scatter_substreams(desc, records, root=0):

@@ -359,6 +359,11 @@ int cabac_hip_split_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
 int cabac_hip_count_emulations_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
                                       const cabac_substream_result *d_results, const uint8_t *d_bytes,
                                       uint32_t *d_counts);
+/* gather: n_seg runs of bin records, run k = d_src[d_src_off[k] .. + d_len[k]) -> d_dst[d_dst_off[k] ..) (offsets in
+ * records; runs must not overlap in d_dst): one launch re-packs the substreams of a batch into the shard of one GPU
+ * (the records side of the ordered-concatenation bookkeeping of bit_stream.cpp:139-150, before coding instead of after). */
+int cabac_hip_gather_records_device(cabac_hip_ctx *ctx, uint32_t n_seg, const uint64_t *d_src_off, const uint64_t *d_dst_off,
+                                    const uint32_t *d_len, const uint16_t *d_src, uint16_t *d_dst);
 
 /* ---- pinned host memory: the device mirrors of the reference's host buffers ------------------------------
  * The reference keeps its byte strings in std::vector FIFOs (OutputBitstream::m_fifo, bit_stream.hpp:16-97;

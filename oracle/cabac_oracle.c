@@ -893,6 +893,74 @@ uint64_t orc_roundtrip_mt(const void *desc, uint32_t first, uint32_t count, cons
   return wall;
 }
 
+/* Digests for bench.py's whole-batch hash: FNV-1a 64 over a substream's coded bytes, then over the four bytes of its bit
+ * count.  orc_digest_mt: of the bytes this restatement produces (finish() + writeByteAlignment()), substreams [first, first +
+ * count) on n_threads threads — the stand-in for oracle/_ref's ref_digest_mt where the reference is not built;
+ * orc_digest_slots: of bytes somebody else produced (the device), substream s at bytes + desc[s].byte_offset with
+ * results[s].n_bits bits.  Returns the number of substreams that failed to encode / 0. */
+static uint64_t fnv_bytes(const uint8_t *p, long n, uint32_t nbits) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (long i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+  for (int i = 0; i < 4; i++) h = (h ^ ((nbits >> (8 * i)) & 0xffu)) * 0x100000001b3ull;
+  return h;
+}
+
+typedef struct {
+  const cabac_substream_desc *desc;
+  const uint16_t *records;
+  uint32_t first, count;
+  atomic_uint next;
+  atomic_ullong bad;
+  uint64_t *digests;
+} digest_job;
+
+static void *digest_worker(void *arg) {
+  digest_job *j = (digest_job *)arg;
+  uint8_t *buf = NULL;
+  long cap = 0;
+  for (;;) {
+    const uint32_t k = atomic_fetch_add(&j->next, 1u);
+    if (k >= j->count) break;
+    const cabac_substream_desc *d = &j->desc[j->first + k];
+    if ((long)d->n_records + 64 > cap) {
+      cap = (long)d->n_records + 64;
+      buf = (uint8_t *)realloc(buf, (size_t)cap);
+    }
+    uint32_t nbits = 0;
+    const long nb = orc_encode_records(j->records + d->rec_offset, d->n_records, d->qp, (int)(d->init_id & 3), 3, buf, cap, &nbits);
+    j->digests[k] = fnv_bytes(buf, nb > 0 ? nb : 0, nbits);
+    if (nb < 0) atomic_fetch_add(&j->bad, 1ull);
+  }
+  free(buf);
+  return NULL;
+}
+
+uint64_t orc_digest_mt(const void *desc, uint32_t first, uint32_t count, const uint16_t *records, int n_threads, uint64_t *digests) {
+  digest_job j;
+  j.desc = (const cabac_substream_desc *)desc;
+  j.records = records;
+  j.first = first;
+  j.count = count;
+  j.digests = digests;
+  atomic_init(&j.next, 0u);
+  atomic_init(&j.bad, 0ull);
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  for (int t = 1; t < n_threads; t++) pthread_create(&th[t], NULL, digest_worker, &j);
+  digest_worker(&j);
+  for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
+  return atomic_load(&j.bad);
+}
+
+void orc_digest_slots(const void *desc_, const uint32_t *results, uint32_t count, const uint8_t *bytes, uint64_t *digests) {
+  const cabac_substream_desc *desc = (const cabac_substream_desc *)desc_;
+  for (uint32_t s = 0; s < count; s++) {
+    const uint32_t nbits = results[2 * s];
+    digests[s] = fnv_bytes(bytes + desc[s].byte_offset, (long)((nbits + 7) / 8), nbits);
+  }
+}
+
 /* ---------------------------------------------------------------- start-code emulation count
  * OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181: greedy scan for
  * 00 00 {00,01,02,03}; search_n(found, end - 1, 2, 0) keeps the zero pair inside [0, n-1); after a hit the

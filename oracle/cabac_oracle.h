@@ -68,6 +68,10 @@ void orc_encode_batch(const void *desc, uint32_t first, uint32_t count, const ui
 void orc_decode_batch(const void *desc, uint32_t first, uint32_t count, const uint16_t *records,
                       const uint8_t *bytes, uint8_t *bins, uint32_t *results);
 
+/* bench.py's whole-batch hash (see cabac_oracle.c) */
+uint64_t orc_digest_mt(const void *desc, uint32_t first, uint32_t count, const uint16_t *records, int n_threads, uint64_t *digests);
+void orc_digest_slots(const void *desc, const uint32_t *results, uint32_t count, const uint8_t *bytes, uint64_t *digests);
+
 /* OutputBitstream::countStartCodeEmulations, common/bit_stream.cpp:157-181 */
 int orc_count_emulations(const uint8_t *bytes, long n);
 

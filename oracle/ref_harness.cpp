@@ -357,6 +357,37 @@ uint64_t ref_roundtrip_mt(const void *desc_, uint32_t first, uint32_t count, con
   return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(w1 - w0).count());
 }
 
+// A digest per substream of the bytes the reference's BinEncoder_Std produces for it (finish() + writeByteAlignment()):
+// FNV-1a 64 over the bytes, then over the four bytes of the bit count.  bench.py compares ALL substreams of its batch with
+// the device's bytes through this (orc_digest_slots computes the same over the device's output).
+uint64_t ref_digest_mt(const void *desc_, uint32_t first, uint32_t count, const uint16_t *records, int n_threads, uint64_t *digests) {
+  const RefDesc *desc = static_cast<const RefDesc *>(desc_);
+  std::atomic<uint32_t> next{0};
+  std::atomic<uint64_t> bad{0};
+  auto worker = [&]() {
+    std::vector<uint8_t> buf;
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= count) break;
+      const RefDesc &d = desc[first + k];
+      buf.resize(size_t(d.n_records) + 64);
+      uint32_t nbits = 0;
+      const long nb = ref_encode_records(records + d.rec_offset, d.n_records, d.qp, int(d.init_id & 3), 3, buf.data(), long(buf.size()), &nbits);
+      uint64_t h = 0xcbf29ce484222325ull;
+      for (long i = 0; i < nb; i++) h = (h ^ buf[size_t(i)]) * 0x100000001b3ull;
+      for (int i = 0; i < 4; i++) h = (h ^ ((nbits >> (8 * i)) & 0xffu)) * 0x100000001b3ull;
+      digests[k] = h;
+      if (nb < 0) bad += 1;
+    }
+  };
+  if (n_threads < 1) n_threads = 1;
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  return bad.load();
+}
+
 // InputBitstream (bit_stream.cpp:183-430) driven by the script format of tests/csrc/host_shim_driver.cpp's
 // shim_input_bitstream_script, so that the host mirror can be compared with it step by step
 long ref_input_bitstream_script(const uint8_t *bytes, long n_bytes, const uint32_t *script, long n_steps, uint32_t *out,

@@ -1,4 +1,4 @@
-"""Differential fuzz of the HIP bin codec against the oracle (GPU box; not collected by pytest: run it by hand).
+"""Differential fuzz of the HIP bin codec against the oracle (GPU box; tests/test_gpu_fuzz.py runs 20 s of it under -m gpu, longer runs by hand).
 
     python3 tests/fuzz_parity.py --seconds 300 [--seed 1] > gpurun_out/fuzz.txt
 
@@ -80,7 +80,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
-    a = ap.parse_args()
+    print(run(ap.parse_args()))
+
+
+def run(a):
+    """a.seconds / a.seed; returns the summary line, raises SystemExit("MISMATCH ...") on the first difference."""
     orc = H.load_oracle()
     hip = H.gpu_ctx()
     t0, rounds, bins = time.time(), 0, 0
@@ -89,7 +93,7 @@ def main():
         seed = a.seed * 1_000_003 + rounds
         rng = np.random.default_rng(seed)
         desc, records, total = draw_batch(rng)
-        enc = int(rng.choice([0, 5, 6, 7]))
+        enc = int(rng.choice([0, 4, 6, 7]))
         hip.set_variant(enc, 0)
         out_o, res_o = orc.encode_batch(desc, records, total)
         out_g, res_g = hip.encode_batch(desc, records, total, check=False)
@@ -128,9 +132,9 @@ def main():
         shapes[key] = shapes.get(key, 0) + 1
         if rounds % 50 == 0:
             print("%d rounds, %.1f M bins, %.0f s" % (rounds, bins / 1e6, time.time() - t0), flush=True)
-    print("fuzz ok: %d rounds, %.1f M bins in %.0f s, seed %d; rounds by batch size (up to): %s"
-          % (rounds, bins / 1e6, time.time() - t0, a.seed, dict(sorted(shapes.items(), key=lambda kv: int(kv[0].split()[0])))))
     hip.close()
+    return ("fuzz ok: %d rounds, %.1f M bins in %.0f s, seed %d; rounds by batch size (up to): %s"
+            % (rounds, bins / 1e6, time.time() - t0, a.seed, dict(sorted(shapes.items(), key=lambda kv: int(kv[0].split()[0])))))
 
 
 if __name__ == "__main__":

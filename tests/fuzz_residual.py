@@ -74,7 +74,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
-    a = ap.parse_args()
+    print(run(ap.parse_args()))
+
+
+def run(a):
+    """a.seconds / a.seed; returns the summary line, raises SystemExit("MISMATCH ...") on the first difference."""
     hip = H.gpu_ctx()
     t0, rounds, coeffs = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
@@ -88,8 +92,8 @@ def main():
         rounds += 1
         if rounds % 5 == 0:
             print("%d rounds, %.1f M coefficients, %.0f s" % (rounds, coeffs / 1e6, time.time() - t0), flush=True)
-    print("fuzz ok: %d rounds (binariser batch + parser batch each), %.1f M coefficients in %.0f s, seed %d" % (rounds, coeffs / 1e6, time.time() - t0, a.seed))
     hip.close()
+    return "fuzz ok: %d rounds (binariser batch + parser batch each), %.1f M coefficients in %.0f s, seed %d" % (rounds, coeffs / 1e6, time.time() - t0, a.seed)
 
 
 if __name__ == "__main__":

@@ -96,3 +96,22 @@ def test_count_emulations_on_crafted_zero_runs():
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
     assert want.max() > 30
     hip.close()
+
+
+def test_pack_shard_gathers_on_the_device():
+    """sharding.pack_shard on a device-resident batch: one gather launch (cabac_hip_gather_records_device) gives the shard the
+    host-side slicing gives — odd and even offsets and lengths, empty substreams, a permuted selection."""
+    import torch
+    from entropy_coding_amd import sharding
+    rng = np.random.default_rng(12)
+    lens = [0, 1, 2, 3, 7, 8, 9, 1000, 1001] + [int(x) for x in rng.integers(0, 5000, size=300)]
+    recs = [rng.integers(0, 1 << 16, size=n, dtype=np.uint16) for n in lens]
+    desc, total = H.make_desc(lens, [30] * len(lens), [2] * len(lens))
+    records = np.concatenate(recs)
+    for trial in range(3):
+        idxs = np.sort(rng.choice(len(lens), size=len(lens) // 2, replace=False)) if trial else np.arange(len(lens))
+        want_d, want_r, want_t = sharding.pack_shard(desc, records, idxs)
+        got_d, got_r, got_t = sharding.pack_shard(desc, torch.from_numpy(records.view(np.int16)).cuda(), idxs)
+        torch.cuda.synchronize()
+        assert np.array_equal(got_d, want_d) and got_t == want_t
+        assert np.array_equal(got_r.cpu().numpy().view(np.uint16), want_r)

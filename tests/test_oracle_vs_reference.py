@@ -152,3 +152,29 @@ def test_count_start_code_emulations():
         a = ref.lib.ref_count_emulations(H._ptr(data, H.u8p), n)
         b = orc.lib.orc_count_emulations(H._ptr(data, H.u8p), n)
         assert a == b, (trial, data.tolist())
+
+
+def test_whole_batch_digests_agree():
+    """bench.py's whole-batch hash: the reference's per-substream digests (ref_digest_mt), the restatement's (orc_digest_mt)
+    and the digest of bytes in slots (orc_digest_slots, what is applied to the device's output) are the same numbers."""
+    import ctypes
+    ref, orc = H.load_ref(), H.load_oracle()
+    rng = np.random.default_rng(31)
+    recs = [H.random_records(rng, int(n)) for n in rng.integers(1, 3000, size=64)]
+    desc, total = H.make_desc([len(r) for r in recs], rng.integers(0, 64, size=64), rng.integers(0, 3, size=64), H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    records = np.concatenate(recs)
+    out, res = orc.encode_batch(desc, records, total)
+    a, b, c = np.zeros(64, np.uint64), np.zeros(64, np.uint64), np.zeros(64, np.uint64)
+    for lib, fn, dst in ((ref.lib, "ref_digest_mt", a), (orc.lib, "orc_digest_mt", b)):
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_uint64
+        f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        assert f(desc.ctypes.data, 0, 64, records.ctypes.data, 3, dst.ctypes.data) == 0
+    g = orc.lib.orc_digest_slots
+    g.restype = None
+    g.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    g(desc.ctypes.data, res.ctypes.data, 64, out.ctypes.data, c.ctypes.data)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and len(set(a.tolist())) == 64
+    out[int(desc["byte_offset"][5]) + 1] ^= 1
+    g(desc.ctypes.data, res.ctypes.data, 64, out.ctypes.data, c.ctypes.data)
+    assert (a != c).sum() == 1 and a[5] != c[5]
