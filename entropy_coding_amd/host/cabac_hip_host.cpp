@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 namespace EntropyCodingAMD {
 
@@ -198,6 +199,10 @@ void BinEncIf::riceStatReset(int bitDepth) {
 // ------------------------------------------------------------------ HipBatch
 HipBatch::HipBatch(int device) : m_device(device) {}
 
+HipBatch::HipBatch(const std::vector<int> &devices) : m_device(devices.empty() ? 0 : devices[0]) {
+  for (size_t k = 1; k < devices.size(); k++) m_peers.emplace_back(new HipBatch(devices[k]));
+}
+
 HipBatch::~HipBatch() { cabac_hip_destroy(m_ctx); }
 
 cabac_hip_ctx *HipBatch::handle() {
@@ -245,10 +250,84 @@ void HipBatch::deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits) {
   if (tail) sink->write(uint32_t(src[whole]) >> (8 - tail), tail);
 }
 
+namespace {
+// longest-processing-time-first: item k (weight w[k]) to the least loaded of n_bins bins; items keep their order in a bin
+std::vector<std::vector<uint32_t>> lptAssign(const std::vector<uint64_t> &w, size_t n_bins) {
+  std::vector<uint32_t> order(w.size());
+  for (uint32_t k = 0; k < order.size(); k++) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+  std::vector<uint64_t> load(n_bins, 0);
+  std::vector<std::vector<uint32_t>> bins(n_bins);
+  for (uint32_t k : order) {
+    const size_t b = size_t(std::min_element(load.begin(), load.end()) - load.begin());
+    bins[b].push_back(k);
+    load[b] += w[k] + 1;
+  }
+  for (auto &b : bins) std::sort(b.begin(), b.end());
+  return bins;
+}
+
+// run job(k) for k = 1 .. n - 1 on threads of their own and job(0) here; the first exception is rethrown after all have ended
+template <class F>
+void onEveryDevice(size_t n, F job) {
+  std::vector<std::exception_ptr> err(n);
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < n; k++)
+    th.emplace_back([&, k] {
+      try {
+        job(k);
+      } catch (...) {
+        err[k] = std::current_exception();
+      }
+    });
+  try {
+    job(0);
+  } catch (...) {
+    err[0] = std::current_exception();
+  }
+  for (std::thread &t : th) t.join();
+  for (const std::exception_ptr &e : err)
+    if (e) std::rethrow_exception(e);
+}
+}  // namespace
+
 void HipBatch::flush() {
   if (m_pending.empty()) return;
   std::vector<Pending> done;
   done.swap(m_pending);
+  if (m_peers.empty()) return flushLocal(done);
+  // several devices: deal the substreams out, longest first, and code every share at the same time
+  std::vector<uint64_t> weight(done.size());
+  for (size_t k = 0; k < done.size(); k++) {
+    weight[k] = done[k].records.size();
+    for (const cabac_tu_desc &t : done[k].blocks) weight[k] += uint64_t(1) << (t.log2_width + t.log2_height);
+  }
+  const std::vector<std::vector<uint32_t>> share = lptAssign(weight, deviceCount());
+  std::vector<std::vector<Pending>> part(deviceCount());
+  size_t moved_blocks = 0;
+  for (size_t dv = 0; dv < share.size(); dv++)
+    for (uint32_t k : share[dv]) {
+      Pending &p = done[k];
+      if (dv > 0 && !p.blocks.empty()) {  // its coefficients move to the staging of the device that will read them
+        HipBatch &peer = *m_peers[dv - 1];
+        for (cabac_tu_desc &t : p.blocks) {
+          const size_t n = size_t(1) << (t.log2_width + t.log2_height);
+          t.coeff_offset = peer.stageCoefficients(m_stageCoeff.data() + t.coeff_offset, n);
+        }
+        moved_blocks += p.blocks.size();
+      }
+      part[dv].push_back(std::move(p));
+    }
+  m_stagedBlocksOpen -= std::min(m_stagedBlocksOpen, moved_blocks);
+  onEveryDevice(deviceCount(), [&](size_t dv) {
+    if (part[dv].empty()) return;
+    if (dv == 0) flushLocal(part[0]);
+    else m_peers[dv - 1]->flushLocal(part[dv]);
+  });
+  if (m_stagedBlocksOpen == 0) m_stageCoeff.clear();
+}
+
+void HipBatch::flushLocal(std::vector<Pending> &done) {
   for (const Pending &p : done)
     if (!p.blocks.empty()) return flushSpliced(done);
   const uint32_t n = uint32_t(done.size());
@@ -472,6 +551,37 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
 void HipBatch::decode(const std::vector<DecodeJob> &jobs, std::vector<std::vector<uint8_t>> &bins,
                       std::vector<uint32_t> *bitsRead) {
   const uint32_t n = uint32_t(jobs.size());
+  if (!m_peers.empty() && n > 1) {  // several devices: the jobs dealt out longest first, every share decoded at the same time
+    std::vector<uint64_t> weight(n);
+    for (uint32_t k = 0; k < n; k++) weight[k] = jobs[k].n_records;
+    const std::vector<std::vector<uint32_t>> share = lptAssign(weight, deviceCount());
+    std::vector<std::vector<DecodeJob>> part(deviceCount());
+    std::vector<std::vector<std::vector<uint8_t>>> part_bins(deviceCount());
+    std::vector<std::vector<uint32_t>> part_bits(deviceCount());
+    for (size_t dv = 0; dv < share.size(); dv++)
+      for (uint32_t k : share[dv]) part[dv].push_back(jobs[k]);
+    onEveryDevice(deviceCount(), [&](size_t dv) {
+      if (part[dv].empty()) return;
+      HipBatch single(dv == 0 ? m_device : m_peers[dv - 1]->m_device);  // (a one-device view of that device's context)
+      HipBatch &owner = dv == 0 ? *this : *m_peers[dv - 1];
+      single.m_ctx = owner.handle();
+      try {
+        single.decode(part[dv], part_bins[dv], &part_bits[dv]);
+      } catch (...) {
+        single.m_ctx = nullptr;
+        throw;
+      }
+      single.m_ctx = nullptr;
+    });
+    bins.assign(n, {});
+    if (bitsRead) bitsRead->assign(n, 0);
+    for (size_t dv = 0; dv < share.size(); dv++)
+      for (size_t i = 0; i < share[dv].size(); i++) {
+        bins[share[dv][i]].swap(part_bins[dv][i]);
+        if (bitsRead) (*bitsRead)[share[dv][i]] = part_bits[dv][i];
+      }
+    return;
+  }
   bins.assign(n, {});
   if (bitsRead) bitsRead->assign(n, 0);
   if (n == 0) return;

@@ -144,6 +144,15 @@ private:
 class HipBatch {
 public:
   explicit HipBatch(int device = 0);
+  // Several GPUs behind one batch (the launcher-free form: every GPU DMAs its share straight from this
+  // process's host memory; no torch.distributed, no collective).  flush() deals the pending substreams to the devices
+  // longest first (LPT by records + coefficients), codes every share on its own device at the same time — one host thread
+  // per device for the duration of the flush — and hands the bytes to each substream's bitstream as a single device
+  // does; the order of the substreams in the caller's bitstreams is the caller's (OutputBitstream::addSubstream,
+  // bit_stream.cpp:139-150), whatever device coded them.  A device may be listed more than once (two contexts on it).
+  // decode() is dealt out the same way; the other calls run on the first device.
+  explicit HipBatch(const std::vector<int> &devices);
+  size_t deviceCount() const { return 1 + m_peers.size(); }
   ~HipBatch();
   HipBatch(const HipBatch &) = delete;
   HipBatch &operator=(const HipBatch &) = delete;
@@ -258,6 +267,8 @@ private:
   ByteVector m_stageBytes;
   std::vector<int32_t, HostAllocator<int32_t>> m_stageCoeff;
   size_t m_stagedBlocksOpen = 0;  // blocks staged by encoders that have not been flushed yet
+  std::vector<std::unique_ptr<HipBatch>> m_peers;  // the other devices of a multi-device batch (each a plain one-device batch)
+  void flushLocal(std::vector<Pending> &done);
   void flushSpliced(std::vector<Pending> &done);
   void deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits);
 };

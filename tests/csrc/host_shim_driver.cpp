@@ -144,12 +144,13 @@ int shim_spliced_streams(int n_streams, const uint32_t *ops, const long *op_off,
                          const int *geom, const int32_t *coeff, const int *qp, const int *init_id, int mode, uint8_t *out,
                          const long *out_off, uint32_t *n_bits, uint32_t *counts) {
   try {
-    HipBatch batch(0);
+    // mode 1: Immediate; mode 2: Deferred on a two-context batch (the coefficients of a share move to its device's staging)
+    HipBatch batch(mode == 2 ? std::vector<int>{0, 0} : std::vector<int>{0});
     std::vector<std::unique_ptr<BinEncoderHip>> enc;
     std::vector<OutputBitstream> bs(n_streams);
     const int32_t *cin = coeff;
     for (int s = 0; s < n_streams; s++) {
-      enc.emplace_back(new BinEncoderHip(batch, mode ? BinEncoderHip::Immediate : BinEncoderHip::Deferred));
+      enc.emplace_back(new BinEncoderHip(batch, mode == 1 ? BinEncoderHip::Immediate : BinEncoderHip::Deferred));
       BinEncoderHip &e = *enc.back();
       e.init(&bs[s]);
       e.reset(qp[s], init_id[s]);
@@ -186,6 +187,49 @@ int shim_spliced_streams(int n_streams, const uint32_t *ops, const long *op_off,
       counts[4 * s + 2] = e.getTrm();
       counts[4 * s + 3] = static_cast<BinEncIf &>(e).getNumBins();
       counts[4 * s] = counts[4 * s + 3] - counts[4 * s + 1] - counts[4 * s + 2];
+    }
+    return 0;
+  } catch (std::exception &e) {
+    strncpy(g_err, e.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
+// GPU: shim_encode_streams through a multi-device HipBatch (devices[0 .. n_dev)), then every substream decoded back through
+// HipBatch::decode on the same batch; bins_ok[s] = 1 if the decoded bins are the recorded ones.
+int shim_multi_device_round_trip(int n_dev, const int *devices, int n_streams, const uint32_t *ops, const long *op_off, const int *qp,
+                                 const int *init_id, uint8_t *out, const long *out_off, uint32_t *n_bits, int *bins_ok) {
+  try {
+    HipBatch batch(std::vector<int>(devices, devices + n_dev));
+    if ((int)batch.deviceCount() != n_dev) return -5;
+    std::vector<std::unique_ptr<BinEncoderHip>> enc;
+    std::vector<OutputBitstream> bs(n_streams);
+    std::vector<RecordVector> recs(n_streams);
+    for (int s = 0; s < n_streams; s++) {
+      enc.emplace_back(new BinEncoderHip(batch));
+      BinEncIf &e = *enc.back();
+      e.init(&bs[s]);
+      e.reset(qp[s], init_id[s]);
+      apply_ops(e, ops + 4 * op_off[s], op_off[s + 1] - op_off[s]);
+      e.encodeBinTrm(1);
+      recs[s] = enc.back()->records();
+      e.finish();
+    }
+    batch.flush();
+    std::vector<HipBatch::DecodeJob> jobs(n_streams);
+    for (int s = 0; s < n_streams; s++) {
+      bs[s].writeByteAlignment();
+      n_bits[s] = bs[s].getNumberOfWrittenBits();
+      if ((long)bs[s].m_fifo.size() > out_off[s + 1] - out_off[s]) return -3;
+      if (!bs[s].m_fifo.empty()) memcpy(out + out_off[s], bs[s].m_fifo.data(), bs[s].m_fifo.size());
+      jobs[s] = HipBatch::DecodeJob{recs[s].data(), uint32_t(recs[s].size()), bs[s].m_fifo.data(), uint32_t(bs[s].m_fifo.size()), qp[s],
+                                    init_id[s], true};
+    }
+    std::vector<std::vector<uint8_t>> bins;
+    batch.decode(jobs, bins);
+    for (int s = 0; s < n_streams; s++) {
+      bins_ok[s] = bins[s].size() == recs[s].size();
+      for (size_t i = 0; bins_ok[s] && i < recs[s].size(); i++) bins_ok[s] = bins[s][i] == (recs[s][i] >> 15);
     }
     return 0;
   } catch (std::exception &e) {

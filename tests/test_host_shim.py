@@ -339,7 +339,7 @@ def test_shim_get_num_written_bits_immediate_mode(drv):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_shim_spliced_residual_blocks(drv, mode):
     """BinEncoderHip::encodeResidual: coefficients handed over where the reference's writer would call residual_coding
     (cabac_writer.cpp:2424-2525), their bins spliced in between the recorded ones on the device at flush().  Bytes and
@@ -388,6 +388,36 @@ def test_shim_spliced_residual_blocks(drv, mode):
         wb, wbits = want[s]
         assert int(nbits[s]) == wbits and np.array_equal(out[int(out_off[s]): int(out_off[s]) + len(wb)], wb), s
         assert tuple(int(x) for x in counts[4 * s: 4 * s + 3]) == want_counts[s] and int(counts[4 * s + 3]) == sum(want_counts[s]), s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_shim_multi_device_batch(drv, n_dev):
+    """HipBatch over several devices (here the same GPU listed n_dev times: n_dev contexts, n_dev host threads at flush): the
+    substreams are dealt out longest first, every share is coded on its own context at the same time, and each substream's
+    bitstream receives exactly the oracle's bytes whatever context coded it; HipBatch::decode deals the jobs out likewise."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(210 + n_dev)
+    n = 37
+    op_list = [H.random_ops(rng, int(x), ctx_frac=0.6, end_trm=False) for x in rng.integers(0, 2500, size=n)]
+    qps, ids = rng.integers(0, 64, size=n), rng.integers(0, 3, size=n)
+    ops = np.concatenate(op_list).astype(np.uint32)
+    op_off = np.concatenate([[0], np.cumsum([len(o) for o in op_list])]).astype(np.int64)
+    out_off = np.concatenate([[0], np.cumsum([64 + 30 * len(o) for o in op_list])]).astype(np.int64)
+    out = np.zeros(int(out_off[-1]), np.uint8)
+    nbits = np.zeros(n, np.uint32)
+    ok = np.zeros(n, np.int32)
+    devs = np.zeros(n_dev, np.int32)
+    drv.shim_multi_device_round_trip.argtypes = [ctypes.c_int, ip, ctypes.c_int, u32p, lp, ip, ip, u8p, lp, u32p, ip]
+    rc = drv.shim_multi_device_round_trip(n_dev, devs.ctypes.data_as(ip), n, H._ptr(ops, u32p), op_off.ctypes.data_as(lp),
+                                          np.asarray(qps, np.int32).ctypes.data_as(ip), np.asarray(ids, np.int32).ctypes.data_as(ip),
+                                          H._ptr(out, u8p), out_off.ctypes.data_as(lp), H._ptr(nbits, u32p), ok.ctypes.data_as(ip))
+    assert rc == 0, drv.shim_last_error()
+    for s, o in enumerate(op_list):
+        full = np.concatenate([o.reshape(-1, 4), np.array([[H.OP_TRM, 1, 0, 0]], np.uint32)])
+        want, wbits, _ = orc.encode_ops(full, int(qps[s]), int(ids[s]), 3)
+        assert wbits == nbits[s] and np.array_equal(out[int(out_off[s]): int(out_off[s]) + len(want)], want), s
+    assert ok.all()
 
 
 @pytest.mark.gpu
