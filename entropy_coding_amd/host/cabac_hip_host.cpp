@@ -197,9 +197,20 @@ void BinEncIf::riceStatReset(int bitDepth) {
 }
 
 // ------------------------------------------------------------------ HipBatch
-HipBatch::HipBatch(int device) : m_device(device) {}
+size_t hostLayoutFingerprint(size_t batch, size_t pending, size_t encoder, size_t estimator, size_t decoder, size_t out, size_t in) {
+  size_t h = 1469598103934665603ull;
+  for (size_t v : {batch, pending, encoder, estimator, decoder, out, in}) h = (h ^ v) * 1099511628211ull;
+  return h;
+}
 
-HipBatch::HipBatch(const std::vector<int> &devices) : m_device(devices.empty() ? 0 : devices[0]) {
+void HipBatch::checkLayout(size_t callers) {
+  const size_t mine = hostLayoutFingerprint(sizeof(HipBatch), sizeof(HipBatch::Pending), sizeof(BinEncoderHip), sizeof(BitEstimatorHip),
+                                            sizeof(BinDecoderHip), sizeof(OutputBitstream), sizeof(InputBitstream));
+  if (callers != mine)
+    fail("this caller was built against another version of cabac_hip_host.hpp than libcabac_hip.so (class layouts differ): rebuild it");
+}
+
+void HipBatch::addPeers(const std::vector<int> &devices) {
   for (size_t k = 1; k < devices.size(); k++) m_peers.emplace_back(new HipBatch(devices[k]));
 }
 

@@ -141,9 +141,16 @@ private:
 
 // ---------------------------------------------------------------------------------------------
 // A session on one GPU: collects finished substreams and codes them in one launch.
+// Objects of these classes are laid out by the caller's compiler from THIS header and filled in by code inside
+// libcabac_hip.so: a caller built against another version of the header (a prebuilt test driver, a plugin) corrupts the heap
+// or the stack without any diagnostic — in round 2 of this repo such a stale test library is the most probable cause of an
+// intermittent SIGABRT at the end of a test run, and in round 3 one segfaulted the same way.  The constructors therefore hand
+// the library the caller's view of the layout, and the library refuses a caller whose view differs from its own.
+size_t hostLayoutFingerprint(size_t batch, size_t pending, size_t encoder, size_t estimator, size_t decoder, size_t out, size_t in);
+
 class HipBatch {
 public:
-  explicit HipBatch(int device = 0);
+  explicit HipBatch(int device = 0) : m_device(device) { checkCaller(); }
   // Several GPUs behind one batch (the launcher-free form: every GPU DMAs its share straight from this
   // process's host memory; no torch.distributed, no collective).  flush() deals the pending substreams to the devices
   // longest first (LPT by records + coefficients), codes every share on its own device at the same time — one host thread
@@ -151,7 +158,10 @@ public:
   // does; the order of the substreams in the caller's bitstreams is the caller's (OutputBitstream::addSubstream,
   // bit_stream.cpp:139-150), whatever device coded them.  A device may be listed more than once (two contexts on it).
   // decode() is dealt out the same way; the other calls run on the first device.
-  explicit HipBatch(const std::vector<int> &devices);
+  explicit HipBatch(const std::vector<int> &devices) : m_device(devices.empty() ? 0 : devices[0]) {
+    checkCaller();
+    addPeers(devices);
+  }
   size_t deviceCount() const { return 1 + m_peers.size(); }
   ~HipBatch();
   HipBatch(const HipBatch &) = delete;
@@ -258,6 +268,9 @@ public:
 
 private:
   friend class BinEncoderHip;
+  inline void checkCaller();  // defined at the end of this header, where every class is complete
+  static void checkLayout(size_t callers);  // throws Exception("... built against another version of cabac_hip_host.hpp")
+  void addPeers(const std::vector<int> &devices);
   int m_device;
   cabac_hip_ctx *m_ctx = nullptr;
   std::vector<Pending> m_pending;
@@ -268,6 +281,9 @@ private:
   std::vector<int32_t, HostAllocator<int32_t>> m_stageCoeff;
   size_t m_stagedBlocksOpen = 0;  // blocks staged by encoders that have not been flushed yet
   std::vector<std::unique_ptr<HipBatch>> m_peers;  // the other devices of a multi-device batch (each a plain one-device batch)
+#ifdef CABAC_HOST_TEST_OTHER_LAYOUT  // tests/test_host_shim.py: a caller compiled from "another version" of this header
+  void *m_memberOfAnotherVersion = nullptr;
+#endif
   void flushLocal(std::vector<Pending> &done);
   void flushSpliced(std::vector<Pending> &done);
   void deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits);
@@ -446,6 +462,11 @@ private:
   int m_qp = 0, m_initId = 0;
   uint32_t m_bitsRead = 0;
 };
+
+inline void HipBatch::checkCaller() {
+  checkLayout(hostLayoutFingerprint(sizeof(HipBatch), sizeof(HipBatch::Pending), sizeof(BinEncoderHip), sizeof(BitEstimatorHip),
+                                    sizeof(BinDecoderHip), sizeof(OutputBitstream), sizeof(InputBitstream)));
+}
 
 }  // namespace EntropyCodingAMD
 #endif

@@ -53,6 +53,9 @@ def build_walk(seed=0xB1A106, n_sub=6):
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
     so = os.path.join(H.ORACLE_DIR, "_ref", "libadapter_test_log.so")
+    newest = max(os.path.getmtime(p) for p in H.HOST_ABI_DEPS if os.path.exists(p))
+    if os.path.getmtime(so) < newest:      # (tests/helpers.py::ref_test_library says why this must not run)
+        raise SystemExit("oracle/_ref/libadapter_test_log.so is older than the host headers it was compiled from: run `make -C oracle`")
     if mode == "gpu":
         from entropy_coding_amd import capi
         capi.load_library()                       # torch's HIP runtime first (see capi.load_library)

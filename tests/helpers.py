@@ -349,7 +349,7 @@ def load_ref():
     """The reference's own sources compiled by oracle/Makefile (build container only)."""
     global _ref
     if _ref is None:
-        so = os.path.join(ORACLE_DIR, "_ref", "libcabac_ref.so")
+        so = ref_test_library("libcabac_ref.so")
         cwd = os.getcwd()
         tmp = tempfile.mkdtemp(prefix="cabac_ref_")  # reference log.cpp:3-4 creates two files in CWD at load
         os.chdir(tmp)
@@ -359,6 +359,33 @@ def load_ref():
             os.chdir(cwd)
         _ref = CodecLib(lib, "ref_")
     return _ref
+
+
+HOST_ABI_DEPS = [os.path.join(ROOT, "entropy_coding_amd", "host", "cabac_hip_host.hpp"),
+                 os.path.join(ROOT, "entropy_coding_amd", "host", "cabac_rem_abs.hpp"),
+                 os.path.join(ROOT, "include", "cabac_hip.h"), os.path.join(ROOT, "integration", "reference_adapter.hpp"),
+                 os.path.join(ROOT, "integration", "reference_adapter_test.cpp"), os.path.join(ROOT, "oracle", "ref_rig.hpp"),
+                 os.path.join(ROOT, "oracle", "ref_harness.cpp")]
+
+
+def ref_test_library(name):
+    """Path of oracle/_ref/<name>, built by oracle/Makefile from the reference's sources and this repo's host headers.  A copy
+    that is older than those headers lays the shim's classes out differently from libcabac_hip.so and corrupts memory without a
+    diagnostic (the SIGABRT of round 2, a segfault in round 3): where the reference's sources are present
+    it is rebuilt, elsewhere (the GPU box, which runs the prebuilt file) a stale one fails the test instead of running."""
+    import pytest
+    so = os.path.join(ORACLE_DIR, "_ref", name)
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/%s not built" % name)
+    deps = HOST_ABI_DEPS[-2:] if name.startswith("libcabac_ref") else HOST_ABI_DEPS   # the reference alone: harness + rig only
+    newest = max(os.path.getmtime(p) for p in deps if os.path.exists(p))
+    if os.path.getmtime(so) < newest:
+        if os.path.isdir("/root/reference/src"):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-j8", "all"], stdout=subprocess.DEVNULL)
+        if os.path.getmtime(so) < newest:
+            pytest.fail("oracle/_ref/%s is older than the host headers it was compiled from: run `make -C oracle` in the build "
+                        "container before sending the tree to the GPU box" % name)
+    return so
 
 
 def gpu_ctx(device=0):

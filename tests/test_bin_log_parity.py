@@ -17,6 +17,7 @@ needs_log_build = pytest.mark.skipif(not os.path.exists(LOG_LIB), reason="ENABLE
 
 
 def _run(mode, tmp_path):
+    H.ref_test_library("libadapter_test_log.so")      # rebuilt here if stale (build container), refused on the GPU box
     out = str(tmp_path / "walk.json")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "bin_log_walk.py"), mode, out],
                        capture_output=True, text=True, timeout=600)

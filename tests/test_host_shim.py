@@ -28,7 +28,10 @@ def drv():
         so = os.path.join(CSRC, "libhost_shim_driver.so")
         src = os.path.join(CSRC, "host_shim_driver.cpp")
         lib = os.path.join(H.ROOT, "entropy_coding_amd", "libcabac_hip.so")
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        hdrs = [os.path.join(H.ROOT, "entropy_coding_amd", "host", h) for h in ("cabac_hip_host.hpp", "cabac_rem_abs.hpp")] + \
+               [os.path.join(H.ROOT, "include", "cabac_hip.h")]
+        # (older than a header = another layout of the shim's classes than the library's: never run, always rebuilt)
+        if not os.path.exists(so) or os.path.getmtime(so) < max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]):
             subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(H.ROOT, "include"),
                                    "-I" + os.path.join(H.ROOT, "entropy_coding_amd", "host"), src,
                                    "-L" + os.path.dirname(lib), "-lcabac_hip", "-Wl,-rpath,$ORIGIN/../../entropy_coding_amd",
@@ -90,6 +93,37 @@ def test_recorder_rejects_bad_arguments(drv):
         counts = np.zeros(4, np.uint32)
         assert drv.shim_record_ops(H._ptr(ops, u32p), 1, H._ptr(rec, u16p), 64, H._ptr(counts, u32p)) == -1
         assert b"ERROR" in drv.shim_last_error()
+
+
+def test_caller_built_from_another_header_version_is_refused(tmp_path):
+    """A caller whose compiler laid the shim's classes out from another version of cabac_hip_host.hpp (here: the same header
+    with one more member in HipBatch) would corrupt memory silently; the constructor hands the library its view of the
+    layout and the library refuses it with an exception before anything else happens."""
+    if os.environ.get("CABAC_TEST_SANITIZED_SHIM"):
+        pytest.skip("runs against the real library")
+    from entropy_coding_amd import capi
+    lib = capi.build_library()
+    src = tmp_path / "stale_caller.cpp"
+    src.write_text("""
+#include <cstring>
+#include "cabac_hip_host.hpp"
+extern "C" int make_batch(char *msg, int cap) {
+  try { EntropyCodingAMD::HipBatch b(0); return 0; }
+  catch (std::exception &e) { strncpy(msg, e.what(), cap - 1); return -1; }
+}
+""")
+    got = {}
+    for name, flag in (("same", []), ("other", ["-DCABAC_HOST_TEST_OTHER_LAYOUT"])):
+        so = str(tmp_path / ("libcaller_%s.so" % name))
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared"] + flag + ["-I" + os.path.join(H.ROOT, "include"),
+                               "-I" + os.path.join(H.ROOT, "entropy_coding_amd", "host"), str(src), "-L" + os.path.dirname(lib),
+                               "-lcabac_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", so])
+        capi.load_library()
+        L = ctypes.CDLL(so)
+        msg = ctypes.create_string_buffer(512)
+        got[name] = (L.make_batch(msg, 512), msg.value.decode())
+    assert got["same"][0] == 0
+    assert got["other"][0] == -1 and "another version of cabac_hip_host.hpp" in got["other"][1]
 
 
 def test_output_bitstream_mirror(drv):

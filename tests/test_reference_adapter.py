@@ -22,10 +22,11 @@ def adp():
     if not SAN:
         from entropy_coding_amd import capi
         capi.load_library()
+    so = SAN or H.ref_test_library("libadapter_test.so")   # rebuilt, or refused, when it is older than the host headers
     cwd = os.getcwd()
     os.chdir(tempfile.mkdtemp(prefix="cabac_ref_"))   # reference log.cpp:3-4 creates bin_log.txt/bit_log.txt in CWD
     try:
-        L = ctypes.CDLL(SO)
+        L = ctypes.CDLL(so)
     finally:
         os.chdir(cwd)
     L.adapter_last_error.restype = ctypes.c_char_p
