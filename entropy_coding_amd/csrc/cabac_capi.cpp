@@ -45,6 +45,7 @@ struct cabac_hip_ctx {
   void *d_buf[kSlots] = {};
   size_t d_cap[kSlots] = {};
   void *h_totals = nullptr;  // pinned, 64 bytes: what the spliced-residual path reads back in the middle
+  uint32_t *d_select = nullptr;  // kMaxChunks + 1 device words: the decode dispatch's on-device choice, one per launch in flight
   // ---- the PCIe path of the host-pointer entry points -------------------------------------------------
   static constexpr int kKernelStreams = 4, kMaxChunks = 8, kBounceDepth = 4;
   static constexpr size_t kBounceBlock = size_t(4) << 20;
@@ -410,6 +411,11 @@ int cabac_hip_init(int device, cabac_hip_ctx **out) {
     return CABAC_HIP_ERR_HIP;
   }
   c->own_stream = true;
+  if (hipMalloc(&c->d_select, 256) != hipSuccess) {
+    (void)hipGetLastError();
+    cabac_hip_destroy(c);
+    return CABAC_HIP_ERR_NOMEM;
+  }
   *out = c;
   return CABAC_HIP_OK;
 }
@@ -421,6 +427,7 @@ void cabac_hip_destroy(cabac_hip_ctx *c) {
   for (int i = 0; i < cabac_hip_ctx::kSlots; i++)
     if (c->d_buf[i]) (void)hipFree(c->d_buf[i]);
   if (c->h_totals) (void)hipHostFree(c->h_totals);
+  if (c->d_select) (void)hipFree(c->d_select);
   pipe_destroy(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -509,7 +516,7 @@ int cabac_hip_decode_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substr
   DeviceGuard g(c->device);
   Bracket br = bracket_for(c, 1);
   HIP_TRY(c, hipEventRecord(br.a, c->stream));
-  HIP_TRY(c, cabac::launch_decode(c->stream, c->dec_variant, n_sub, d_desc, d_records, d_bytes, d_bins, d_results));
+  HIP_TRY(c, cabac::launch_decode(c->stream, c->dec_variant, n_sub, d_desc, d_records, d_bytes, d_bins, d_results, 0, c->d_select));
   HIP_TRY(c, hipEventRecord(br.b, c->stream));
   c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
@@ -821,7 +828,7 @@ static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
     const bool ring = !c->prof_ev.empty() && c->prof_n < c->prof_kind.size();
     Bracket br = ring ? bracket_for(c, 1) : Bracket{nullptr, nullptr};
     if (ring) HIP_TRY(c, hipEventRecord(br.a, ks));
-    HIP_TRY(c, cabac::launch_decode(ks, c->dec_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_bins, d_res + ch.s0, n_sub));
+    HIP_TRY(c, cabac::launch_decode(ks, c->dec_variant, n_k, d_desc + ch.s0, d_rec, d_slots, d_bins, d_res + ch.s0, n_sub, c->d_select + 1 + k));
     if (ring) HIP_TRY(c, hipEventRecord(br.b, ks));
     c->timed = false;
     HIP_TRY(c, hipMemcpyAsync(h_res + ch.s0, d_res + ch.s0, n_k * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, ks));

@@ -16,7 +16,7 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
                          const uint16_t *records, uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
                          const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
-                         cabac_substream_result *results, uint32_t in_flight = 0);
+                         cabac_substream_result *results, uint32_t in_flight = 0, uint32_t *select = nullptr);
 
 // v4 "quad" kernels (cabac_kernels_v4.hip): four substreams per wave
 hipError_t launch_encode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
@@ -25,8 +25,12 @@ hipError_t launch_encode_v6(hipStream_t st, uint32_t n_sub, const cabac_substrea
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
 hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             uint8_t *bytes, cabac_substream_result *results, uint32_t in_flight = 0);
+// lanes_per_sub: 16 = the quad decoder (four substreams per wave), 4 = sixteen substreams per wave, 0 = by the batch: from
+// 9 216 substreams in flight the choice is made on the device (select: one device word of the caller's, not shared with
+// another launch in flight; null = the quad decoder)
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight = 0);
+                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight = 0,
+                            int lanes_per_sub = 16, uint32_t *select = nullptr);
 
 // bit estimator (cabac_kernels_v4.hip)
 hipError_t launch_estimate(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,

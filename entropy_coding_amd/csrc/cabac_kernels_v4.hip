@@ -41,6 +41,14 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, true);  // bound_ctrl: no old-value init
 }
 
+// lane I of every group of L lanes -> all lanes of that group: L = 16 the DPP row broadcast above, L = 4 a DPP quad
+// permutation (quad_perm:[I,I,I,I])
+template <int L, int I>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
+  if constexpr (L == 16) return row_bcast<I>(v);
+  else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true);
+}
+
 // Lanes (of `lanes`) that hold the same BITS-bit key as this lane.  One ballot per key bit; each lane keeps
 // the lanes that agree with it on that bit: m &= ~(ballot ^ mybit), with the lane's bit spread to a 0 / ~0
 // word so that the whole round is four vector instructions (bfe, cmp, 2 x bitop3) and no scalar one.
@@ -1348,12 +1356,14 @@ __device__ __forceinline__ void quad_dec_check(QuadDec &w, bool second) {
   w.q_lo = w.ring[at + 1u];  // at == 63: dword 64 mirrors dword 0
 }
 
-// staging, part 1 (a step whose number is 0 mod 4): request the next 64-byte block if it is wanted
+// staging, part 1 (a step whose number is 0 mod 4): request the next block (one dword per lane of the substream: 64 bytes
+// with 16 lanes, 16 with 4 — four steps of L bins consume at most 3 L bytes) if it is wanted
+template <int L = 16>
 __device__ __forceinline__ void quad_dec_stage_load(QuadDec &w, uint32_t j) {
   w.pf_mask = neg_mask(w.filled - w.rp - 128u);  // fewer than 128 bytes ahead (filled >= rp always)
   w.pf_off = w.filled + 4u * j;
   w.pf_data = *reinterpret_cast<const uint32_t *>(w.src_safe + min(w.pf_off, w.last_dword));
-  w.filled += 64u & w.pf_mask;
+  w.filled += (4u * L) & w.pf_mask;
 }
 // part 2 (the step after): into the ring; past the end of the substream the window is fed zeros
 __device__ __forceinline__ void quad_dec_stage_store(QuadDec &w) {
@@ -1377,12 +1387,13 @@ constexpr uint32_t kRingStride = 66;  // 64 ring dwords + the mirror of dword 0 
 // park them in LDS and every lane reads its row's sixteen back with four 16-byte reads per field — an LDS read of one
 // address by all lanes of a row IS the broadcast, and it replaces one v_mov_b32_dpp per bin and field (the consumers are
 // VOP3 / VOPC / SDWA encodings that cannot take a DPP operand themselves).
+template <int L = 16>
 struct QuadDecRow {
-  uint32_t c2[16], ctxm[16], srmul[16], ep[16], key[16];
+  uint32_t c2[L], ctxm[L], srmul[L], ep[L], key[L];
 };
 
-template <int I, bool kSpecial>
-__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDecRow &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+template <int I, bool kSpecial, int L = 16>
+__device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDecRow<L> &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                               uint32_t &bits, QuadDec &w) {
   // Input check only every 4th bin (4 bins consume at most 24 bits): 16-bit units are appended while fewer than
   // 32 look-ahead bits are valid.  The question is asked here, the answer acted upon at the END of this step: a
@@ -1396,7 +1407,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
     asm volatile("" : "+s"(refill), "+s"(refill2));
   }
   // the state of this bin's context, from the lane that holds the record; state() / getLPS, contexts.cpp:939-950
-  const uint32_t st = row_bcast<I>(st_v);
+  const uint32_t st = group_bcast<L, I>(st_v);
   const uint32_t sum = (st & 0xffffu) + (st >> 16);  // the low half carries no rate bits here (see the kernel)
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
@@ -1423,16 +1434,16 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   uint32_t nsh = (uint32_t)__builtin_clz(x) - 23u;
   uint32_t keep = ngem;
   if (kSpecial) {
-    keep |= ~row_bcast<I>(f.ntrm);                               // terminate bin 1 leaves value untouched (:184-185)
-    nsh &= ngem | row_bcast<I>(f.ntrm);                          // ... and does not renormalise
+    keep |= ~group_bcast<L, I>(f.ntrm);                               // terminate bin 1 leaves value untouched (:184-185)
+    nsh &= ngem | group_bcast<L, I>(f.ntrm);                          // ... and does not renormalise
   }
   w.hi = sel(keep, w.hi, e);
   w.range = x << nsh;
   if (kSpecial) {
-    w.range = sel(row_bcast<I>(f.alm), 256u, w.range);
+    w.range = sel(group_bcast<L, I>(f.alm), 256u, w.range);
     // After a terminate bin 1 nothing but finish() follows; keep range >= 256 so that the no-op steps past the
     // end of the substream (t = 0, rm = range) never look like a renormalising MPS step.
-    w.range |= 256u & ~(ngem | row_bcast<I>(f.ntrm));
+    w.range |= 256u & ~(ngem | group_bcast<L, I>(f.ntrm));
   }
   {
     // (as DPP operands of their VOP2 consumers srmul and ep would cost no move, but hipcc then pads every such consumer
@@ -1462,12 +1473,15 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   }
 }
 
-template <bool kSpecial>
-__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, const QuadDecRow &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
+template <bool kSpecial, int L = 16>
+__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, const QuadDecRow<L> &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
                                                uint32_t &bits, QuadDec &w) {
-#define QSTEP(I) quad_dec_step<I, kSpecial>(f, u, r0_v, a_v, st_v, bits, w)
-  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3); QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
-  QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+#define QSTEP(I) quad_dec_step<I, kSpecial, L>(f, u, r0_v, a_v, st_v, bits, w)
+  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3);
+  if constexpr (L == 16) {
+    QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
+    QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+  }
 #undef QSTEP
 }
 
@@ -1475,23 +1489,32 @@ __device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, const QuadD
 // pins "one chain wave per SIMD" instead of leaving it to where the dispatcher happens to put
 // single-wave workgroups (measured: the same decode kernel ran 2.06 ms or 3.3 ms depending on the geometry
 // of the kernel launched before it).
-template <int W>
+// L lanes per substream, 64 / L substreams per wave, L bins per step.  L = 16 is the quad decoder; L = 4 ("hex": sixteen
+// substreams per wave, the state of bin I of a step broadcast inside its quad of lanes by a DPP quad permutation) trades a
+// longer chain per bin — the per-step work is spread over 4 bins instead of 16 — for four times the substreams per
+// instruction: the geometry for batches that offer more than one quad wave per SIMD (launch_decode_v4).
+// select (may be null): the launch runs only if *select == want — the dispatch launches both geometries behind
+// decode_select_kernel, which looks at the batch on the device (the descriptors of a *_device call are not on the host).
+template <int W, int L = 16>
 __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                            const uint16_t *__restrict__ records,
                                                            const uint8_t *__restrict__ bytes, uint8_t *__restrict__ bins,
-                                                           cabac_substream_result *__restrict__ results) {
+                                                           cabac_substream_result *__restrict__ results,
+                                                           const uint32_t *__restrict__ select, uint32_t want) {
+  if (select != nullptr && *select != want) return;
   // decode keeps the two window sizes of a context (they never change) apart from its state word, whose low
   // five bits are then zero: state() is one SDWA add of the two halves, without masking
-  __shared__ uint32_t ctx_all[W * kQuadSubs * kQuadCtxStride];
+  constexpr uint32_t kSubs = 64u / L;  // substreams per wave
+  __shared__ uint32_t ctx_all[W * kSubs * kQuadCtxStride];
   // what a record id means for the chain, looked up instead of computed (one 32-byte entry per id, the same for every
   // substream: the window sizes of a context do not depend on QP or slice type): {c2, srmul, ctxm, ep | r0_v, a_v, ntrm, alm}
   __shared__ __attribute__((aligned(16))) uint32_t rec_tab[512][8];
-  __shared__ uint32_t ring_all[W * kQuadSubs * kRingStride];
+  __shared__ uint32_t ring_all[W * kSubs * kRingStride];
   __shared__ uint32_t field_all[W][5][64];  // the record fields of a step on their way from lane I to the row (QuadDecRow)
   const uint32_t wave = threadIdx.x >> 6;
-  uint32_t *ctx = ctx_all + wave * (kQuadSubs * kQuadCtxStride);
-  const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
-  const uint32_t sub = (blockIdx.x * W + wave) * kQuadSubs + row;
+  uint32_t *ctx = ctx_all + wave * (kSubs * kQuadCtxStride);
+  const uint32_t lane = threadIdx.x & 63u, row = lane / L, j = lane % L;
+  const uint32_t sub = (blockIdx.x * W + wave) * kSubs + row;
   const bool live = sub < n_sub;
   const cabac_substream_desc d = desc[live ? sub : 0];
   const uint32_t n = live ? d.n_records : 0u;
@@ -1501,7 +1524,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   {
     const int qp = d.qp < 0 ? 0 : (d.qp > 63 ? 63 : d.qp);
     const uint32_t iid = d.init_id & 3u;
-    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += 16) {
+    for (uint32_t k = j; k < (uint32_t)kNumCtx; k += L) {
       const uint32_t packed = ctx2_init(qp, c_init_tables[iid * kNumCtx + k], c_init_tables[3 * kNumCtx + k]);
       rctx[k] = packed & ~31u;
     }
@@ -1541,12 +1564,12 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     w.lo = first << 31;
   }
   w.look = 16;
-  // the first 192 bytes go into the ring at once (three blocks); the window itself started from bytes 0..3
-  w.ring = ring_all + (wave * kQuadSubs + row) * kRingStride;
-  for (uint32_t blk = 0; blk < 3; blk++) {
-    w.filled = 64u * blk;
+  // the first 192 bytes go into the ring at once (blocks of 4 L bytes); the window itself started from bytes 0..3
+  w.ring = ring_all + (wave * kSubs + row) * kRingStride;
+  for (uint32_t blk = 0; blk < 192u / (4u * L); blk++) {
+    w.filled = 4u * L * blk;
     w.rp = 0;  // "wanted"
-    quad_dec_stage_load(w, j);
+    quad_dec_stage_load<L>(w, j);
     w.pf_mask = ~0u;
     quad_dec_stage_store(w);
   }
@@ -1562,8 +1585,8 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // scalar unit wait for the vector result (~55 cycles each, per step).  The longest row's length is made
   // scalar once; loads past the end of a row read a valid address and are ignored (`active`).
   uint32_t n_wave = n;
-  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 16));
-  n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, 32));
+#pragma unroll
+  for (int d = L; d < 64; d <<= 1) n_wave = max(n_wave, (uint32_t)__shfl_xor((int)n_wave, d));
   const uint32_t max_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_wave);
   const uint16_t *rec_safe = n != 0 ? rec : reinterpret_cast<const uint16_t *>(desc);
   const uint32_t last_rec = n != 0 ? n - 1u : 0u;
@@ -1571,7 +1594,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   // the fields of the chain parked in LDS and read back per row (QuadDecRow), the choice of the step variant, the context
   // states — is prepared in two stages off the top of the step: the table rows are requested at the START of the step
   // before (they arrive during its chain), the rest at its END (the context store has just been written back).
-  uint32_t rec1 = rec_safe[min(j, last_rec)], rec2 = rec_safe[min(16u + j, last_rec)], rec3 = rec_safe[min(32u + j, last_rec)];
+  uint32_t rec1 = rec_safe[min(j, last_rec)], rec2 = rec_safe[min(L + j, last_rec)], rec3 = rec_safe[min(2u * L + j, last_rec)];
   uint32_t prev_bin = 0, prev_idx = ~0u;  // the bins of the previous step, not yet stored
   uint64_t prev_lanes = 0;                 // ... and the lanes that have one
   uint32_t nxt_id, nxt_actm;
@@ -1580,7 +1603,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     uint32_t r = rec1;               // loaded two steps ago
     rec1 = rec2;
     rec2 = rec3;
-    rec3 = rec_safe[min(base + 48u + j, last_rec)];
+    rec3 = rec_safe[min(base + 3u * L + j, last_rec)];
     nxt_actm = neg_mask(base + j - n);                              // ~0: a record of this substream
     nxt_id = sel(nxt_actm, r & CABAC_REC_ID_MASK, 0x1f0u);         // past the end: an id that is nothing
     const uint4 *row4 = reinterpret_cast<const uint4 *>(rec_tab[nxt_id]);
@@ -1590,7 +1613,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   uint32_t cur_id, cur_stored, cur_ctxm, cur_r0v, cur_av;
   uint64_t cur_special;
   QuadDecInfo f;
-  QuadDecRow u;
+  QuadDecRow<L> u;
   auto prepare = [&]() {              // stage 2 for the step requested last
     const uint32_t id = nxt_id, ctxm = nxt_a.z;
     cur_id = id;
@@ -1616,10 +1639,10 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    auto fetch = [&](uint32_t which, uint32_t (&dst)[16]) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * 16u]);
+    auto fetch = [&](uint32_t which, uint32_t (&dst)[L]) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * L]);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < L / 4; q++) {
         const uint4 v = p[q];
         dst[4 * q] = v.x;
         dst[4 * q + 1] = v.y;
@@ -1635,30 +1658,30 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   };
   request(0);
   prepare();
-  for (uint32_t base = 0; base < max_n; base += 16) {
+  for (uint32_t base = 0; base < max_n; base += L) {
     V5_TICK(t0);
     V5_TICK(t1);
     // The bins of the previous step are stored only now, after the wait at the end of that step: loads and stores share
     // one in-order counter, so a store issued before a wait would add its whole latency to it (the same goes for the
     // input block requested a step ago: into the ring with it before anything new is issued)
-    if ((base & 48u) == 16u) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
+    if ((base & (3u * L)) == L) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
     {  // under the lane mask asked for at the end of the step before: an `if` here is a compare the scalar unit waits for
       uint64_t saved;
       asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_byte %2, %3, off\n\ts_mov_b64 exec, %0"
                    : "=&s"(saved) : "s"(prev_lanes), "v"(out + min(prev_idx, last_rec)), "v"(prev_bin) : "memory");
     }
-    if ((base & 48u) == 0u) quad_dec_stage_load(w, j);    // steps 0, 4, 8, ...: request a block of input
+    if ((base & (3u * L)) == 0u) quad_dec_stage_load<L>(w, j);    // steps 0, 4, 8, ...: request a block of input
     const uint32_t id = cur_id, ctxm = cur_ctxm;
     // asked long ago, needed now (the choice of the step variant): the branch finds the answer waiting
     uint64_t special = cur_special;
     asm volatile("" : "+s"(special));
     uint32_t st_v = cur_stored & ctxm;
     const uint32_t a_v = cur_av, r0_v = cur_r0v;
-    request(base + 16u);                                  // the ids and table rows of the next step
+    request(base + L);                                  // the ids and table rows of the next step
     uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
     V5_TICK(t2);
-    if (special == 0) quad_dec_steps<false>(f, u, r0_v, a_v, st_v, bits, w);
-    else quad_dec_steps<true>(f, u, r0_v, a_v, st_v, bits, w);
+    if (special == 0) quad_dec_steps<false, L>(f, u, r0_v, a_v, st_v, bits, w);
+    else quad_dec_steps<true, L>(f, u, r0_v, a_v, st_v, bits, w);
     V5_TICK(t3);
     const uint32_t my_bin = (bits >> j) & 1u;
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
@@ -1691,7 +1714,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   }
   if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;
   const uint64_t bad_mask = __ballot(bad != 0);
-  if ((bad_mask >> (row * 16u)) & 0xffffull) flags |= CABAC_RES_BAD_RECORD;
+  if ((bad_mask >> (row * L)) & ((1ull << L) - 1ull)) flags |= CABAC_RES_BAD_RECORD;
   if (live && j == 0) {
     cabac_substream_result res;
     res.n_bits = 8u * bytes_read + (uint32_t)bits_needed;
@@ -1833,14 +1856,65 @@ hipError_t launch_encode_v7(hipStream_t st, uint32_t n_sub, const cabac_substrea
   return hipGetLastError();
 }
 
+// How many substreams of the longest one's length the batch is worth: sum of n_records / max n_records.  The sixteen-per-wave
+// geometry pays when the chip is offered more than two quad waves per SIMD of EQUAL work; a batch whose time is that of a
+// few long substreams (BASELINE config C5: 4 096 long ones among 8 192) is better off with the shorter chain per bin of the
+// quad decoder.  *select = 1: sixteen per wave, 0: four.
+__global__ __launch_bounds__(1024) void decode_select_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                             uint32_t threshold, uint32_t *__restrict__ select) {
+  __shared__ unsigned long long sum_w[16];
+  __shared__ uint32_t max_w[16];
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (uint32_t s = threadIdx.x; s < n_sub; s += 1024u) {
+    const uint32_t n = desc[s].n_records;
+    sum += n;
+    mx = max(mx, n);
+  }
+  for (int d = 1; d < 64; d <<= 1) {
+    sum += __shfl_xor(sum, d);
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    sum_w[threadIdx.x >> 6] = sum;
+    max_w[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; k++) {
+      sum += sum_w[k];
+      mx = max(mx, max_w[k]);
+    }
+    *select = (mx != 0 && sum >= (unsigned long long)threshold * mx) ? 1u : 0u;
+  }
+}
+
+constexpr uint32_t kHexFrom = 9216;  // measured (tools/batch_scaling.py): 8 192 equal substreams 2.12 ms quad / 2.23 ms hex, 12 288: 3.14 / 2.23
+
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
-                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight) {
+                            const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight, int lanes_per_sub,
+                            uint32_t *select) {
+  if (lanes_per_sub == 0) {  // auto
+    if (max(n_sub, in_flight) < kHexFrom || select == nullptr) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 16);
+    // enough substreams for the sixteen-per-wave geometry IF they are about equally long: asked on the device, both
+    // geometries launched, the one not chosen returns at once
+    // (a chunk of a bigger batch in flight is judged by its share of the threshold)
+    const uint32_t thr = (uint32_t)((uint64_t)kHexFrom * n_sub / max(n_sub, in_flight));
+    hipLaunchKernelGGL(decode_select_kernel, dim3(1), dim3(1024), 0, st, n_sub, desc, thr, select);
+    hipLaunchKernelGGL((decode_kernel_v4<4, 4>), dim3((n_sub + 63u) / 64u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results, select, 1u);
+    hipLaunchKernelGGL((decode_kernel_v4<4, 16>), dim3((n_sub + 15u) / 16u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results, select, 0u);
+    return hipGetLastError();
+  }
   const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  if ((max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs >= 1024u) {
+  if (lanes_per_sub == 4) {  // sixteen substreams per wave, 64 per workgroup (one workgroup's LDS fills most of a CU)
+    hipLaunchKernelGGL((decode_kernel_v4<4, 4>), dim3((n_sub + 63u) / 64u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results,
+                       (const uint32_t *)nullptr, 0u);
+  } else if ((max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs >= 1024u) {
     hipLaunchKernelGGL(decode_kernel_v4<4>, dim3((waves + 3) / 4), dim3(256), 0, st, n_sub, desc, records, bytes, bins,
-                       results);
+                       results, (const uint32_t *)nullptr, 0u);
   } else {
-    hipLaunchKernelGGL(decode_kernel_v4<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results);
+    hipLaunchKernelGGL(decode_kernel_v4<1>, dim3(waves), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results,
+                       (const uint32_t *)nullptr, 0u);
   }
   return hipGetLastError();
 }

@@ -17,14 +17,14 @@ pytestmark = pytest.mark.gpu
 
 # auto = the dispatch (encode v7 from 3 072 substreams, v6 below; decode v4); 4 / 6 / 7 force one encoder generation
 # (the generations v1-v3 and v5 were retired in round 3: cabac_hip_set_variant refuses them)
-VARIANTS = {"auto": 0, "v4": 4, "v6": 6, "v7": 7}
+# decode: 4 = the quad decoder (four substreams per wave), 8 = sixteen substreams per wave (dispatched for big batches)
+VARIANTS = {"auto": (0, 0), "v4": (4, 4), "v6": (6, 0), "v7": (7, 0), "dec16": (0, 8)}
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
 def hip(request):
     c = H.gpu_ctx()   # raises without a GPU: there is no fallback
-    v = VARIANTS[request.param]
-    c.set_variant(v, v if v in (0, 4) else 0)        # one decoder generation is dispatched (v4); DECODE_VARIANTS below
+    c.set_variant(*VARIANTS[request.param])
     c.variant_name = request.param
     yield c
     c.close()
@@ -319,6 +319,41 @@ def test_probe_reports_num_written_bits(hip):
         assert np.array_equal(_stream_bytes(out, desc, res, s), _stream_bytes(out_o, desc, res_o, s)), s
 
 
+@pytest.mark.parametrize("mix", ["equal", "few_long"])
+def test_decode_dispatch_on_big_batches(mix):
+    """From 9 216 substreams in flight the decode dispatch asks the device whether the batch is worth that many equally long
+    substreams (decode_select_kernel) and launches both geometries, one of which returns at once: 10 000 about equally long
+    substreams take the sixteen-per-wave kernel, 10 000 of which 500 are forty times as long the quad kernel.  Either way the
+    bins, bit counts and flags are the oracle's — through the device-pointer call and the chunked host-pointer call."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(4 if mix == "equal" else 5)
+    n_sub = 10000
+    lens = rng.integers(150, 250, size=n_sub)
+    if mix == "few_long":
+        lens[rng.choice(n_sub, size=500, replace=False)] = 8000
+    lens[7] = 0
+    recs = [H.random_records(rng, max(int(n) - 1, 0), end_trm=(n > 0)) for n in lens]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=n_sub), rng.integers(0, 3, size=n_sub), H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    dd = desc.copy()
+    dd["byte_capacity"] = (res_o["n_bits"] + 7) // 8
+    bins_o, ro = orc.decode_batch(dd, records, out_o)
+    hip = H.gpu_ctx()
+    for chunks in ("0", "2"):
+        os.environ["CABAC_HIP_CHUNKS"] = chunks
+        try:
+            c = capi.CabacHip(0)
+            bins, rd = c.decode_batch(dd, records, out_o, check=False)
+            c.close()
+        finally:
+            del os.environ["CABAC_HIP_CHUNKS"]
+        assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"]) and not rd["flags"].any()
+        assert np.array_equal(bins, bins_o) and np.array_equal(bins, (records >> 15).astype(np.uint8))
+    hip.close()
+
+
 def test_retired_variants_are_refused():
     """Variant numbers of the retired generations fail loudly at launch instead of falling back to another kernel."""
     desc, total = H.make_desc([4], [30], [2], H.SUB_FINISH)
@@ -336,7 +371,7 @@ import sys, numpy as np
 sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
 import helpers as H
 from entropy_coding_amd import capi
-hip = capi.CabacHip(0); hip.set_variant(%(enc)d, 0)
+hip = capi.CabacHip(0); hip.set_variant(%(enc)d, %(dec)d)
 orc = H.load_oracle()
 rng = np.random.default_rng(4242)
 # ragged lengths incl. empty and single-record substreams, a too small buffer and a bad record, in one batch that
@@ -376,13 +411,13 @@ print("OK")
 '''
 
 
-@pytest.mark.parametrize("enc", [0, 6, 7])
-def test_ragged_batches_above_and_below_the_big_batch_geometries(enc):
+@pytest.mark.parametrize("enc,dec", [(0, 0), (6, 0), (7, 0), (0, 8)])
+def test_ragged_batches_above_and_below_the_big_batch_geometries(enc, dec):
     """The same ragged batches (37 and 4 100 substreams: empty and one-record substreams, a bad record, a buffer that is too
     small, an incomplete last workgroup) through the dispatched encoders: 4 100 substreams take the 16-substream workgroups
     of v7 (auto, 7) and the four-unit workgroups of v6 (6), 37 the one-unit workgroups."""
     import subprocess
     import sys
-    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT, "enc": enc}
+    code = _UNITS_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": H.ROOT, "enc": enc, "dec": dec}
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
