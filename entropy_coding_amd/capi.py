@@ -23,7 +23,7 @@ assert DESC_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 8
 TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_height", "u1"), ("channel", "u1"),
                      ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
 assert TU_DTYPE.itemsize == 16
-TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM = 1, 2, 4, 8, 16
+TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM, TU_SBT_ZERO_OUT = 1, 2, 4, 8, 16, 32
 TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
 TU_INFO_TS = 0x20000
 SPLICE_DTYPE = np.dtype([("at", "<u4"), ("tu", "<u4")])          # cabac_splice

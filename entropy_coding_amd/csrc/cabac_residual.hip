@@ -319,6 +319,12 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     return kStage ? stage[stage_base + (y << lwe) + x] : coeff[(y << lw) + x];
   };
 
+  // SBT / MTS zero-out (CABAC_TU_SBT_ZERO_OUT; cabac_writer.cpp:2660-2667, :2507-2516, unit.cpp:465-479): a 32-wide (32-tall)
+  // luma block is coded as if only its left (upper) 16 columns (rows) existed
+  const bool zo = !kTs && live && (flags & CABAC_TU_SBT_ZERO_OUT) && chroma == 0u && w <= 32u && h <= 32u;
+  const uint32_t zo_w = (zo && w == 32u) ? 16u : we, zo_h = (zo && h == 32u) ? 16u : he;
+  auto zeroed_out = [&](uint32_t gpos) { return (((gpos & 15u) << cgw_l2) >= zo_w) || (((gpos >> 4) << cgh_l2) >= zo_h); };
+  uint64_t zo_groups = 0;  // by scan index: groups the walk passes over without a flag
   // ---- sweep 1: which groups hold a coefficient, and the last significant position ----------------------
   int last = -1;
   uint64_t coded = 0;    // by scan index of the group
@@ -333,7 +339,9 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
       int32_t c = 0;
       uint32_t gpos = 0;
       if (on) gpos = grid[k];
-      if (on && lane_in_cg) c = coef_at(((gpos & 15u) << cgw_l2) + ix, ((gpos >> 4) << cgh_l2) + iy);
+      const bool out_of_play = on && zeroed_out(gpos);
+      if (out_of_play) zo_groups |= 1ull << k;
+      if (on && !out_of_play && lane_in_cg) c = coef_at(((gpos & 15u) << cgw_l2) + ix, ((gpos >> 4) << cgh_l2) + iy);
       const uint32_t nz = row_bits(c != 0, row_shift);
       if (nz) {
         if (last < 0) last = (int)(((uint32_t)k << cg_l2) + (31u - (uint32_t)__builtin_clz(nz)));
@@ -365,7 +373,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     const uint32_t off_x = chroma ? 0u : luma_off_x, off_y = chroma ? 0u : luma_off_y;
     const uint32_t sh_x = chroma ? min(w >> 3, 2u) : (lw + 1u) >> 2, sh_y = chroma ? min(h >> 3, 2u) : (lh + 1u) >> 2;
     const uint32_t gix = group_idx(px), giy = group_idx(py);
-    const uint32_t nx = gix + (gix < group_idx(we - 1u) ? 1u : 0u), ny = giy + (giy < group_idx(he - 1u) ? 1u : 0u);
+    const uint32_t nx = gix + (gix < group_idx(zo_w - 1u) ? 1u : 0u), ny = giy + (giy < group_idx(zo_h - 1u) ? 1u : 0u);
     const uint32_t sx = gix > 3u ? (gix - 2u) >> 1 : 0u, sy = giy > 3u ? (giy - 2u) >> 1 : 0u;
     if (kWrite) {
       if (l < nx) out[off + l] = (uint16_t)((l < gix ? CABAC_REC_BIN : 0u) | (CABAC_CTX_LAST_X(chroma) + off_x + (l >> sh_x)));
@@ -378,7 +386,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
   // ---- sweep 2: the coefficient groups in coding order ----------------------------------------------
   const bool dq = !kTs && live && (flags & CABAC_TU_DEP_QUANT);  // state transitions 32040 (cabac_writer.cpp:2482), else state 0
-  int budget = (int)((we * he * 28u) >> 4);              // cabac_writer.cpp:2485-2489
+  int budget = (int)((zo_w * zo_h * 28u) >> 4);          // cabac_writer.cpp:2485-2489 (the area after the zero-out)
   uint32_t state = 0;
   const int last_cg = live ? (last >> cg_l2) : -1;
   // Only groups that hold a coefficient (and group 0) are walked; the empty ones in between cost one group flag
@@ -392,10 +400,29 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     todo &= ~(1ull << cg);
     // coded_sub_block_flag (cabac_writer.cpp:2733-2743) of the empty groups passed over, then of this group
     const uint32_t gap = row_on ? (uint32_t)(prev_cg - 1 - cg) : 0u;
-    if (kWrite) {
+    uint32_t gap_flags = gap;  // flags actually coded: the zeroed-out groups among those passed over have none
+    if (__ballot(zo && gap != 0u) != 0ull) {
+      uint32_t kept = 0;
       for (uint32_t base = 0; __ballot(base < gap) != 0ull; base += 16u) {
         const uint32_t j = base + l;
-        if (j < gap) {
+        const bool in_gap = j < gap;
+        const uint32_t sp = in_gap ? grid[prev_cg - 1 - (int)j] : 0u;
+        const bool keep = in_gap && !zeroed_out(sp);
+        const uint32_t m_keep = row_bits(keep, row_shift);
+        if (kWrite && keep) {
+          const uint32_t sx_ = sp & 15u, sy_ = sp >> 4, sb = sy_ * wg + sx_;
+          const uint32_t right = sx_ + 1u < wg ? (uint32_t)(sig_map >> (sb + 1u)) & 1u : 0u;
+          const uint32_t below = sy_ + 1u < hg ? (uint32_t)(sig_map >> (sb + wg)) & 1u : 0u;
+          out[off + kept + (uint32_t)__builtin_popcount(m_keep & ((1u << l) - 1u))] = (uint16_t)(CABAC_CTX_SIG_COEFF_GROUP(chroma) + (right | below));
+        }
+        kept += (uint32_t)__builtin_popcount(m_keep);
+      }
+      gap_flags = zo ? kept : gap;
+    }
+    if (kWrite && __ballot(!zo && gap != 0u) != 0ull) {
+      for (uint32_t base = 0; __ballot(!zo && base < gap) != 0ull; base += 16u) {
+        const uint32_t j = base + l;
+        if (!zo && j < gap) {
           const uint32_t sp = grid[prev_cg - 1 - (int)j];
           const uint32_t sx_ = sp & 15u, sy_ = sp >> 4, sb = sy_ * wg + sx_;
           const uint32_t right = sx_ + 1u < wg ? (uint32_t)(sig_map >> (sb + 1u)) & 1u : 0u;
@@ -404,7 +431,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
         }
       }
     }
-    off += gap;
+    off += gap_flags;
     prev_cg = row_on ? cg : prev_cg;
     const uint32_t gpos = row_on ? grid[cg] : 0u;
     const uint32_t gx = gpos & 15u, gy = gpos >> 4;
@@ -538,6 +565,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
           else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
         }
         uint16_t *o1 = out + off + spent_before;  // every position above a context-coded one is context coded
+#ifndef CABAC_EXP_NO_CTX
         if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_FLAG(set) + ofs));
         if (nzero) {
           *o1++ = (uint16_t)((a > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(2u + chroma) + aofs));
@@ -547,11 +575,14 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
             *o1 = (uint16_t)(((rem >> 1) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(chroma) + aofs));
           }
         }
+#endif
       }
       uint16_t *o2 = out + off + n_ctx_bins + before23;
+#ifndef CABAC_EXP_NO_EP
       for (uint32_t j = 0; j < ep.len1; j++) o2[j] = (uint16_t)((((ep.code1 >> (ep.len1 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
       o2 += ep.len1;
       for (uint32_t j = 0; j < ep.len2; j++) o2[j] = (uint16_t)((((ep.code2 >> (ep.len2 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
+#endif
       if (nzero && !hidden)
         out[off + n_ctx_bins + total23 + (uint32_t)__builtin_popcount(m_nz & above_mask)] = (uint16_t)((c < 0 ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
     }

@@ -344,7 +344,10 @@ __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk
   const uint32_t luma_off_y = g.lh < 3u ? 0u : g.lh == 3u ? 3u : g.lh == 4u ? 6u : g.lh == 5u ? 10u : 15u;
   const uint32_t off_x = chroma ? 0u : luma_off_x, off_y = chroma ? 0u : luma_off_y;
   const uint32_t sh_x = chroma ? min((1u << g.lw) >> 3, 2u) : (g.lw + 1u) >> 2, sh_y = chroma ? min((1u << g.lh) >> 3, 2u) : (g.lh + 1u) >> 2;
-  const uint32_t max_x = group_idx(g.we - 1u), max_y = group_idx(g.he - 1u);
+  // SBT / MTS zero-out (CABAC_TU_SBT_ZERO_OUT; cabac_reader.cpp:2880-2891, :2718-2727, unit.cpp:465-479)
+  const bool zo = (g.fl & CABAC_TU_SBT_ZERO_OUT) && chroma == 0u && g.lw <= 5u && g.lh <= 5u;
+  const uint32_t zo_w = (zo && g.lw == 5u) ? 16u : g.we, zo_h = (zo && g.lh == 5u) ? 16u : g.he;
+  const uint32_t max_x = group_idx(zo_w - 1u), max_y = group_idx(zo_h - 1u);
   uint32_t px = 0, py = 0;
   for (; px < max_x; px++) {
     pd_check(d);
@@ -379,7 +382,7 @@ __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk
   const uint32_t gt1_base = SL_A(CABAC_CTX_GTX_FLAG(2u + chroma)), par_base = SL_A(CABAC_CTX_PAR_FLAG(chroma)),
                  gt2_base = SL_A(CABAC_CTX_GTX_FLAG(chroma));
   uint32_t sq = 0;
-  int32_t budget = (int32_t)((g.we * g.he * 28u) >> 4);
+  int32_t budget = (int32_t)((zo_w * zo_h * 28u) >> 4);
   uint64_t sig_map = 0;
   PP_TICK(p1);
   PP_ADD(1, p0, p1);
@@ -387,6 +390,7 @@ __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk
   for (int32_t cg = (int32_t)last_cg; cg >= 0; cg--) {
     PP_TICK(c0);
     const uint32_t gp = rl(gl, (uint32_t)cg), gx = gp & 15u, gy = gp >> 4, gbit = gy * g.wg + gx;
+    if ((gx << g.cgw_l2) >= zo_w || (gy << g.cgh_l2) >= zo_h) continue;  // zeroed out: nothing is coded for this group
     bool sig = cg == (int32_t)last_cg || cg == 0;
     if (!sig) {  // coded_sub_block_flag (cabac_reader.cpp:2965-2975)
       const uint32_t right = gx + 1u < g.wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;

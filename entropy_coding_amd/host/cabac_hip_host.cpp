@@ -235,7 +235,7 @@ cabac_tu_desc makeTuDesc(const HipBatch::ResidualBlock &b, uint64_t coeff_offset
   t.channel = b.chroma ? 1 : 0;
   t.flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
                     (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
-                    (b.transformSkip && b.bdpcm ? CABAC_TU_BDPCM : 0u));
+                    (b.transformSkip && b.bdpcm ? CABAC_TU_BDPCM : 0u) | (b.sbtZeroOut && !b.transformSkip ? CABAC_TU_SBT_ZERO_OUT : 0u));
   t.max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
   return t;
 }
@@ -525,7 +525,7 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
       t.channel = b.chroma ? 1 : 0;
       t.flags = uint8_t((b.depQuant ? CABAC_TU_DEP_QUANT : 0u) | (b.signHiding ? CABAC_TU_SIGN_HIDING : 0u) |
                         (b.tsFlag ? CABAC_TU_TS_FLAG : 0u) | (b.transformSkip ? CABAC_TU_TRANSFORM_SKIP : 0u) |
-                        (b.bdpcm ? CABAC_TU_BDPCM : 0u));
+                        (b.bdpcm ? CABAC_TU_BDPCM : 0u) | (b.sbtZeroOut ? CABAC_TU_SBT_ZERO_OUT : 0u));
       t.max_log2_tr_range = uint8_t(b.maxLog2TrDynamicRange);
       tus.push_back(t);
       coeff_total += uint64_t(b.width) * b.height;

@@ -200,7 +200,7 @@ public:
 
   // Residual binariser: the bin records CABACWriter::residual_coding (cabac_writer.cpp:2424-2525) would ask its bin
   // encoder for, for many transform blocks in one launch.  Regular and transform-skip residual coding (no SBT/MTS
-  // zero-out, no range-extension Rice derivation).  Throws Exception("Coefficient coding called for empty
+  // zero-out included, no range-extension Rice derivation).  Throws Exception("Coefficient coding called for empty
   // TU") for an all-zero block, as the reference's CHECK does (cabac_writer.cpp:2458).
   struct ResidualBlock {
     const int32_t *coeff;  // width * height coefficients, raster (TransformUnit::getCoeffs(compID).buf)
@@ -211,6 +211,7 @@ public:
     bool tsFlag;           // TU::isTSAllowed: code transform_skip_flag first (1 for a transform-skip block)
     bool transformSkip = false;  // mtsIdx == MTS_SKIP with TS residual coding enabled: residual_codingTS
     bool bdpcm = false;          // with transformSkip: cu.bdpcmMode / bdpcmModeChroma
+    bool sbtZeroOut = false;     // SPS::getUseMTS() && cu.sbtInfo != 0 (luma, at most 32 x 32): cabac_writer.cpp:2660-2667, :2507-2516
     int maxLog2TrDynamicRange = 15;
   };
   struct ResidualResult {

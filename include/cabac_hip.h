@@ -241,8 +241,8 @@ int cabac_hip_binarize_device(cabac_hip_ctx *ctx, uint32_t n_sub, const uint64_t
  * reverse scan order, residual_coding_subblock (:2722-2872) with the context selection of CoeffCodingContext
  * (context_modelling.hpp:71-244, context_modelling.cpp:7-106) and the scans of rom.cpp:148-260.
  * Regular residual coding and transform-skip residual coding (residual_codingTS, cabac_writer.cpp:2874-3046, with
- * BDPCM); SBT/MTS zero-out and the range extensions (extended Rice derivation, persistent Rice adaptation, TSRC Rice)
- * are not covered.
+ * BDPCM) and the SBT/MTS zero-out (CABAC_TU_SBT_ZERO_OUT); the range extensions (extended Rice derivation, persistent Rice
+ * adaptation, TSRC Rice) are not covered.
  * One block = one cabac_tu_desc; coefficients are int32 (the reference's TCoeff), raster, stride = width.
  * For blocks wider/taller than 32 only the top-left 32x32 region is coded (rom.cpp:218-226). */
 typedef struct cabac_tu_desc {
@@ -261,6 +261,12 @@ typedef struct cabac_tu_desc {
 #define CABAC_TU_TRANSFORM_SKIP 0x8u /* mtsIdx == MTS_SKIP and TS residual coding enabled: residual_codingTS
                                       * (cabac_writer.cpp:2874-3046) instead of the regular walk; blocks up to 32 x 32  */
 #define CABAC_TU_BDPCM 0x10u      /* with TRANSFORM_SKIP: cu.bdpcmMode / bdpcmModeChroma != 0                  */
+#define CABAC_TU_SBT_ZERO_OUT 0x20u /* SPS::getUseMTS() && cu.sbtInfo != 0, a luma block of at most 32 x 32 that is not transform-skip
+                                     * coded: a 32-wide (32-tall) block is coded as if only its left (upper) 16 columns (rows) existed —
+                                     * the prefix of last_sig_coeff stops at g_groupIdx[15] (cabac_writer.cpp:2660-2667,
+                                     * cabac_reader.cpp:2880-2891), coefficient groups beyond are passed over without a flag (:2507-2516,
+                                     * cabac_reader.cpp:2718-2727), and the budget of context-coded bins follows the reduced area
+                                     * (TransformUnit::getTbAreaAfterCoefZeroOut, unit.cpp:465-479).  No effect on other block sizes.   */
 
 /* d_info[t] (may be NULL): scanPosLast in bits 15..0, what residual_coding records in its CUCtx argument */
 #define CABAC_TU_INFO_LAST_MASK 0xFFFFu
@@ -420,8 +426,8 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
  * Block flags (cabac_tu_desc.flags): DEP_QUANT, SIGN_HIDING as for the binariser; CABAC_TU_TS_FLAG: transform_skip_flag
  * is in the stream (TU::isTSAllowed) and the block is parsed as that bin says, whatever CABAC_TU_TRANSFORM_SKIP says;
  * without it CABAC_TU_TRANSFORM_SKIP decides (the reference infers the flag for BDPCM blocks); CABAC_TU_BDPCM:
- * cu.bdpcmMode / bdpcmModeChroma.  Transform-skip blocks up to 32 x 32.  SBT/MTS zero-out and the range extensions are
- * not covered.
+ * cu.bdpcmMode / bdpcmModeChroma; CABAC_TU_SBT_ZERO_OUT as for the binariser.  Transform-skip blocks up to 32 x 32.  The range
+ * extensions are not covered.
  * d_tu_info[t] (may be NULL): for a regular block scanPosLast | CABAC_TU_INFO_MTS_VIOLATION — what residual_coding
  * leaves in its CUCtx argument (:2675-2693, :2729-2732) follows from it —, for a block parsed as transform skip
  * CABAC_TU_INFO_TS (the reader sets mtsIdx = MTS_SKIP).

@@ -230,8 +230,8 @@ private:
 // same bins into the bin encoder, same CUCtx side effects.  `residual_coding` is the drop-in for one block (one launch
 // per call: for checking, not for speed); `queue` + `flush` is the shape a writer uses — blocks queued while the
 // syntax walk runs, one launch for all of them, each block's bins handed to the encoder in order.
-// Covered: regular and transform-skip residual coding (with BDPCM).  Not covered (throws): the SBT/MTS zero-out of
-// last_sig_coeff and the range extensions (Rice extension, persistent Rice adaptation, TSRC Rice).
+// Covered: regular and transform-skip residual coding (with BDPCM), the SBT/MTS zero-out.  Not covered (throws): the range
+// extensions (Rice extension, persistent Rice adaptation, TSRC Rice).
 //
 // Two forms.  On a BinEncoderHipRef (second constructor) a block costs the host one copy of its coefficients and one
 // pass over them for the CUCtx side effects: ts_flag is recorded as an ordinary bin, the coefficients are staged, a splice
@@ -263,7 +263,8 @@ public:
                      sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag() ||
                      (it.transformSkip && sps.getSpsRangeExtension().getTSRCRicePresentFlag()),
                  "range-extension Rice derivation is not covered by the GPU binariser");
-    HIPREF_CHECK(sps.getUseMTS() && tu.cu->sbtInfo != 0, "SBT zero-out is not covered by the GPU binariser");
+    // SBT / MTS zero-out of 32-wide / tall luma blocks (cabac_writer.cpp:2660-2667, :2507-2516, unit.cpp:465-479)
+    it.sbtZeroOut = sps.getUseMTS() && tu.cu->sbtInfo != 0 && compID == COMPONENT_Y && tu.blocks[compID].width <= 32 && tu.blocks[compID].height <= 32;
     const CompArea &blk = tu.blocks[compID];
     it.width = blk.width;
     it.height = blk.height;
@@ -293,6 +294,7 @@ public:
       b.tsFlag = false;  // coded below through the encoder
       b.transformSkip = it.transformSkip;
       b.bdpcm = it.bdpcm;
+      b.sbtZeroOut = it.sbtZeroOut;
       b.maxLog2TrDynamicRange = it.maxLog2;
       blocks.push_back(b);
     }
@@ -331,6 +333,7 @@ private:
     std::vector<int32_t> coeff;
     unsigned width = 0, height = 0;
     bool chroma = false, depQuant = false, signHiding = false, tsAllowed = false, notSkip = true, transformSkip = false, bdpcm = false;
+    bool sbtZeroOut = false;
     unsigned tsFlag = 0;
     int maxLog2 = 15;
     Common::CUCtx *cuCtx = nullptr;
@@ -381,6 +384,7 @@ private:
     b.tsFlag = false;
     b.transformSkip = it.transformSkip;
     b.bdpcm = it.bdpcm;
+    b.sbtZeroOut = it.sbtZeroOut;
     b.maxLog2TrDynamicRange = it.maxLog2;
     const bool regular = !it.transformSkip;
     const bool luma = !it.chroma;
@@ -494,7 +498,7 @@ private:
 // terminate bin and the stop pattern (end_of_slice / finish) and moves the bitstream on.  The device decoder cannot stop
 // in the middle of a substream and hand over to the host, so this binds where a substream (or the residual partition of
 // one) holds nothing but residual blocks whose sizes are known before their coefficients; INTEGRATION.md section 6.
-// Not covered (throws): SBT zero-out, the range extensions, TS residual coding disabled by the slice.
+// Not covered (throws): the range extensions, TS residual coding disabled by the slice.
 class ResidualParserHipRef {
 public:
   explicit ResidualParserHipRef(HipBatch &batch) : m_batch(batch) {}
@@ -515,7 +519,6 @@ public:
                      sps.getSpsRangeExtension().getPersistentRiceAdaptationEnabledFlag() ||
                      sps.getSpsRangeExtension().getTSRCRicePresentFlag(),
                  "range-extension Rice derivation is not covered by the GPU parser");
-    HIPREF_CHECK(sps.getUseMTS() && tu.cu->sbtInfo != 0, "SBT zero-out is not covered by the GPU parser");
     HIPREF_CHECK(tu.cs->slice->getTSResidualCodingDisabledFlag(), "slice_ts_residual_coding_disabled_flag is not covered by the GPU parser");
     Item it;
     it.tu = &tu;
@@ -531,6 +534,8 @@ public:
     it.b.bdpcm = (isLuma(compID) ? tu.cu->bdpcmMode : tu.cu->bdpcmModeChroma) != 0;
     it.b.tsFlag = TU::isTSAllowed(tu, compID);
     it.b.transformSkip = it.b.bdpcm || tu.mtsIdx[compID] == MTS_SKIP;
+    it.b.sbtZeroOut = sps.getUseMTS() && tu.cu->sbtInfo != 0 && compID == COMPONENT_Y && tu.blocks[compID].width <= 32 &&
+                      tu.blocks[compID].height <= 32;  // cabac_reader.cpp:2880-2891, :2718-2727
     it.b.maxLog2TrDynamicRange = sps.getMaxLog2TrDynamicRange(toChannelType(compID));
     m_items.push_back(it);
   }

@@ -1271,6 +1271,9 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
     return n_ts;
   }
 
+  /* SBT / MTS zero-out (cabac_writer.cpp:2660-2667, :2507-2516, unit.cpp:465-479): a 32-wide (tall) luma block coded as 16 */
+  const int zo = (flags & CABAC_TU_SBT_ZERO_OUT) && !chroma && g.w <= 32 && g.h <= 32;
+  const int zo_w = zo && g.w == 32 ? 16 : (g.w < 32 ? g.w : 32), zo_h = zo && g.h == 32 ? 16 : (g.h < 32 ? g.h : 32);
   { /* last significant position, cabac_writer.cpp:2639-2720 */
     const unsigned px = (unsigned)SX(last), py = (unsigned)SY(last);
     static const uint8_t luma_off[7] = {0, 0, 0, 3, 6, 10, 15};
@@ -1283,7 +1286,7 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
       sh_x = (unsigned)(lw + 1) >> 2; sh_y = (unsigned)(lh + 1) >> 2;
     }
     const unsigned gx = last_group_idx(px), gy = last_group_idx(py);
-    const unsigned max_x = last_group_idx((unsigned)(g.w < 32 ? g.w : 32) - 1), max_y = last_group_idx((unsigned)(g.h < 32 ? g.h : 32) - 1);
+    const unsigned max_x = last_group_idx((unsigned)zo_w - 1), max_y = last_group_idx((unsigned)zo_h - 1);
     for (unsigned k = 0; k < gx; k++) rs_put(&r, CABAC_CTX_LAST_X(chroma) + off_x + (k >> sh_x), 1);
     if (gx < max_x) rs_put(&r, CABAC_CTX_LAST_X(chroma) + off_x + (gx >> sh_x), 0);
     for (unsigned k = 0; k < gy; k++) rs_put(&r, CABAC_CTX_LAST_Y(chroma) + off_y + (k >> sh_y), 1);
@@ -1294,7 +1297,7 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
 
   const unsigned trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u; /* cabac_writer.cpp:2482 */
   int state = 0;
-  int budget = (((g.w < 32 ? g.w : 32) * (g.h < 32 ? g.h : 32)) * 28) >> 4; /* :2485-2489 */
+  int budget = ((zo_w * zo_h) * 28) >> 4; /* :2485-2489 */
   const int last_cg = last >> g.cg_l2;
   (void)n_cg;
 
@@ -1302,6 +1305,7 @@ long orc_residual_records(int lw, int lh, int chroma, unsigned flags, int max_lo
     const int lo = cg << g.cg_l2, hi = lo + cg_size - 1;
     const int cgx = SX(lo) >> g.cgw_l2, cgy = SY(lo) >> g.cgh_l2;
     const int coded_group = cg_sig[cgy * g.wg + cgx];
+    if ((cgx << g.cgw_l2) >= zo_w || (cgy << g.cgh_l2) >= zo_h) continue; /* zeroed out: no flag, no coefficients (:2507-2516) */
     if (cg != last_cg && cg != 0) {
       const int right = cgx + 1 < g.wg ? cg_sig[cgy * g.wg + cgx + 1] : 0;
       const int below = cgy + 1 < g.hg ? cg_sig[(cgy + 1) * g.wg + cgx] : 0;
@@ -1534,7 +1538,10 @@ static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff, uint
   } else {
     sh_x = (unsigned)(lw + 1) >> 2; sh_y = (unsigned)(lh + 1) >> 2;
   }
-  const unsigned max_x = last_group_idx((unsigned)we - 1), max_y = last_group_idx((unsigned)he - 1);
+  /* SBT / MTS zero-out (cabac_reader.cpp:2880-2891, :2718-2727, unit.cpp:465-479) */
+  const int zo = (flags & CABAC_TU_SBT_ZERO_OUT) && !chroma && g.w <= 32 && g.h <= 32;
+  const int zo_w = zo && g.w == 32 ? 16 : we, zo_h = zo && g.h == 32 ? 16 : he;
+  const unsigned max_x = last_group_idx((unsigned)zo_w - 1), max_y = last_group_idx((unsigned)zo_h - 1);
   unsigned px = 0, py = 0;
   while (px < max_x && dec_bin(d, CABAC_CTX_LAST_X(chroma) + off_x + (px >> sh_x))) px++;
   while (py < max_y && dec_bin(d, CABAC_CTX_LAST_Y(chroma) + off_y + (py >> sh_y))) py++;
@@ -1546,13 +1553,14 @@ static int parse_block(bin_dec *d, const cabac_tu_desc *tu, int32_t *coeff, uint
   info_bits = (uint32_t)last;
 
   const unsigned trans = (flags & CABAC_TU_DEP_QUANT) ? 32040u : 0u;
-  int state = 0, budget = (we * he * 28) >> 4;
+  int state = 0, budget = (zo_w * zo_h * 28) >> 4;
   uint8_t cg_sig[64];
   memset(cg_sig, 0, sizeof cg_sig);
   const int cg_size = 1 << g.cg_l2, last_cg = last >> g.cg_l2;
   for (int cg = last_cg; cg >= 0; cg--) {
     const int lo = cg << g.cg_l2, hi = lo + cg_size - 1;
     const int cgx = SX(lo) >> g.cgw_l2, cgy = SY(lo) >> g.cgh_l2;
+    if ((cgx << g.cgw_l2) >= zo_w || (cgy << g.cgh_l2) >= zo_h) continue; /* zeroed out: nothing is coded for it */
     int sig = cg == last_cg || cg == 0;
     if (!sig) {
       const int right = cgx + 1 < g.wg ? cg_sig[cgy * g.wg + cgx + 1] : 0;

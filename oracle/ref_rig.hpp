@@ -29,6 +29,7 @@ struct ResidualRig {
   }
   // flags: bit0 dep_quant, bit1 sign_data_hiding, bit2 transform skip enabled in the SPS (max size 32),
   //        bit4 the block is transform-skip coded (mtsIdx = MTS_SKIP), bit5 BDPCM (cu.bdpcmMode / bdpcmModeChroma),
+  //        bit6 SBT with MTS enabled in the SPS (sps.useMTS, cu.sbtInfo != 0): the zero-out of 32-wide / tall luma blocks,
   //        bits 8..15: if non-zero, extended_precision_processing with this bit depth.  comp: 0 Y, 1 Cb, 2 Cr.
   void make_tu(Common::TransformUnit &tu, std::vector<Common::TCoeff> &buf, int width, int height, int comp, int flags,
                const int32_t *coeff) {
@@ -37,6 +38,8 @@ struct ResidualRig {
     slice->m_signDataHidingEnabledFlag = (flags >> 1) & 1;
     sps->m_transformSkipEnabledFlag = (flags >> 2) & 1;
     sps->m_log2MaxTransformSkipBlockSize = 5;
+    sps->m_MTS = (flags >> 6) & 1;
+    cu->sbtInfo = (flags >> 6) & 1;
     const int depth = (flags >> 8) & 0xff;
     sps->m_spsRangeExtension.m_extendedPrecisionProcessingFlag = depth != 0;
     sps->m_bitDepths.recon[0] = sps->m_bitDepths.recon[1] = depth ? depth : 10;

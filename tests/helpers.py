@@ -41,7 +41,7 @@ RESULT_DTYPE = np.dtype([("n_bits", "<u4"), ("flags", "<u4")])
 # cabac_tu_desc and friends (include/cabac_hip.h)
 TU_DTYPE = np.dtype([("coeff_offset", "<u8"), ("log2_width", "u1"), ("log2_height", "u1"), ("channel", "u1"),
                      ("flags", "u1"), ("max_log2_tr_range", "u1"), ("reserved", "u1", (3,))])
-TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM = 1, 2, 4, 8, 16
+TU_DEP_QUANT, TU_SIGN_HIDING, TU_TS_FLAG, TU_TRANSFORM_SKIP, TU_BDPCM, TU_SBT_ZERO_OUT = 1, 2, 4, 8, 16, 32
 TU_INFO_MTS_VIOLATION, TU_INFO_EMPTY, TU_INFO_BAD_DESC = 0x10000, 0x80000000, 0x40000000
 TU_INFO_TS = 0x20000
 
@@ -235,7 +235,8 @@ class CodecLib:
         info = np.zeros(8, np.int32)
         assert max_log2_range == 15 or 17 <= max_log2_range <= 20   # min(20, bit depth + 6) under extended precision
         depth = 0 if max_log2_range == 15 else max_log2_range - 6
-        rig = (flags & 7) | (8 if with_cuctx else 0) | (0x10 if flags & TU_TRANSFORM_SKIP else 0) | (0x20 if flags & TU_BDPCM else 0)
+        rig = (flags & 7) | (8 if with_cuctx else 0) | (0x10 if flags & TU_TRANSFORM_SKIP else 0) | (0x20 if flags & TU_BDPCM else 0) | \
+              (0x40 if flags & TU_SBT_ZERO_OUT else 0)
         n = f(w, h, 1 if chroma else 0, rig | depth << 8, _ptr(coeff, i32p), _ptr(out, u16p), cap,
               _ptr(info, i32p))
         if n == -1:
@@ -273,7 +274,7 @@ class CodecLib:
             # rig flags (oracle/ref_rig.hpp): bit0 dep_quant, bit1 sign hiding, bit2 transform skip enabled (flag coded),
             # bit4 the block is transform-skip coded, bit5 BDPCM
             rig = np.array([(fl & 3) | (4 if fl & TU_TS_FLAG else 0) | (0x10 if fl & TU_TRANSFORM_SKIP else 0) |
-                            (0x20 if fl & TU_BDPCM else 0) for _, _, _, fl in blocks_meta], np.int32)
+                            (0x20 if fl & TU_BDPCM else 0) | (0x40 if fl & TU_SBT_ZERO_OUT else 0) for _, _, _, fl in blocks_meta], np.int32)
             assert not any((fl & TU_TS_FLAG) and (fl & TU_BDPCM) for _, _, _, fl in blocks_meta), \
                 "with BDPCM the reference does not code transform_skip_flag"
             wh = np.array([[w, h] for w, h, _, _ in blocks_meta], np.int32).ravel()

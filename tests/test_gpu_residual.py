@@ -279,3 +279,25 @@ def test_many_random_blocks_of_every_kind(hip):
             flags.append(fl & ~H.TU_TS_FLAG if max(w, h) > 32 else fl)
         chromas.append(int(rng.integers(0, 2)))
     check_against_oracle(hip, blocks, chromas, flags)
+
+
+def test_sbt_zero_out_blocks(hip):
+    """CABAC_TU_SBT_ZERO_OUT: 32-wide / 32-tall luma blocks coded as their left / upper 16 (last-position clamp, groups passed
+    over without a flag, reduced budget: cabac_writer.cpp:2660-2667, :2507-2516, unit.cpp:465-479) against the oracle — which
+    test_residual_oracle.py pins to the reference's writer —, mixed with blocks the flag leaves alone, both passes."""
+    rng = np.random.default_rng(0x5B7)
+    shapes = [(32, 32), (32, 8), (8, 32), (32, 16), (16, 32), (32, 4), (4, 32), (32, 2), (2, 32), (32, 1), (16, 16), (8, 8), (4, 4), (64, 64)]
+    blocks, chromas, flags = [], [], []
+    for k in range(600):
+        w, h = shapes[k % len(shapes)]
+        ch = 1 if k % 11 == 10 else 0
+        c = H.random_block(rng, w, h, density=[0.05, 0.4, 1.0][k % 3], big=[0.0, 0.2, 0.6][(k // 3) % 3], huge=0.05 if k % 17 == 0 else 0.0)
+        if not ch and max(w, h) <= 32:
+            if w == 32:
+                c[:, 16:] = 0
+            if h == 32:
+                c[16:, :] = 0
+            if not c.any():
+                c[0, min(w, 16) - 1] = -2
+        blocks.append(c); chromas.append(ch); flags.append(int(rng.integers(0, 4)) | H.TU_SBT_ZERO_OUT)
+    check_against_oracle(hip, blocks, chromas, flags, slack=3)

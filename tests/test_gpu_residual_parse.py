@@ -319,3 +319,38 @@ def test_host_pointer_parse_batch(hip):
         hip.residual_parse_batch(bad, buf, first, tus, off)
     co2, res2 = hip.residual_parse_batch(bad, buf, first, tus, off, check=False)
     assert int(res2["flags"][3]) & H.RES_UNDERRUN and not res2["flags"][[0, 1, 2, 4]].any()
+
+
+def test_sbt_zero_out_blocks_parse_back(hip):
+    """CABAC_TU_SBT_ZERO_OUT on the parser's side (cabac_reader.cpp:2880-2891, :2718-2727): substreams of zero-out blocks mixed
+    with blocks the flag does not touch come back as the oracle's parser — pinned to the reference's reader — gives them."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng(0x5B8)
+    shapes = [(32, 32), (32, 8), (8, 32), (32, 16), (16, 32), (32, 4), (4, 32), (16, 16), (8, 8), (4, 4), (64, 32)]
+    subs, qps = [], rng.integers(10, 50, 60)
+    for s in range(60):
+        blocks, metas = [], []
+        for k in range(int(rng.integers(1, 10))):
+            w, h = shapes[int(rng.integers(0, len(shapes)))]
+            ch = int(rng.random() < 0.15)
+            c = H.random_block(rng, w, h, density=float(rng.choice([0.05, 0.4, 1.0])), big=float(rng.choice([0.0, 0.3])))
+            if not ch and max(w, h) <= 32:
+                if w == 32:
+                    c[:, 16:] = 0
+                if h == 32:
+                    c[16:, :] = 0
+                if not c.any():
+                    c[0, 0] = 1
+            blocks.append(c)
+            metas.append((w, h, ch, (H.TU_DEP_QUANT if s & 1 else 0) | H.TU_SBT_ZERO_OUT))
+        rec = np.concatenate([orc.residual_records(c, metas[i][2], metas[i][3])[0] for i, c in enumerate(blocks)] + [np.array([0x81FF], np.uint16)])
+        data, _ = orc.encode_records(rec, int(qps[s]), 2, 3)
+        subs.append((metas, blocks, data))
+    got, res = parse(hip, subs, qps)
+    assert not res["flags"].any()
+    for s, (metas, blocks, data) in enumerate(subs):
+        rc, want, nbits = orc.residual_decode(data, int(qps[s]), metas)
+        assert rc == 0 and int(res["n_bits"][s]) == nbits, s
+        for k, c in enumerate(blocks):
+            we, he = min(metas[k][0], 32), min(metas[k][1], 32)
+            assert np.array_equal(got[s][k][:he, :we], c[:he, :we]) and np.array_equal(got[s][k][:he, :we], want[k][:he, :we]), (s, k)

@@ -287,3 +287,59 @@ def test_golden_parse_substreams():
         assert np.array_equal(np.concatenate([d.ravel() for d in dec]), g["s%d_coeff" % s]), s
         for k, m in enumerate(metas):      # mtsIdx / CUCtx as the reference reader left them
             _expected_info(g["s%d_refinfo" % s][k], m[0], m[1], m[2], int(info[k]))
+
+
+def _sbt_block(rng, w, h, density, big=0.1):
+    """A luma block as an encoder with SBT + MTS leaves it: nothing outside the left 16 columns of a 32-wide block / the upper
+    16 rows of a 32-tall one (unit.cpp:465-479)."""
+    c = H.random_block(rng, w, h, density=density, big=big)
+    if w == 32:
+        c[:, 16:] = 0
+    if h == 32:
+        c[16:, :] = 0
+    if not c.any():
+        c[0, 0] = 3
+    return c
+
+
+@needs_ref
+def test_sbt_zero_out_matches_reference():
+    """CABAC_TU_SBT_ZERO_OUT (sps.getUseMTS() && cu.sbtInfo != 0, luma, at most 32 x 32): the clamp of the last position's
+    prefix (cabac_writer.cpp:2660-2667), the coefficient groups passed over without a flag (:2507-2516) and the budget of the
+    reduced area (unit.cpp:465-479) — records and CUCtx against the reference's writer, bytes -> coefficients against its
+    reader (cabac_reader.cpp:2880-2891, :2718-2727); chroma blocks and small blocks are not affected by the flag."""
+    orc, ref = H.load_oracle(), H.load_ref()
+    rng = np.random.default_rng(0x5B7)
+    shapes = [(32, 32), (32, 8), (8, 32), (32, 16), (16, 32), (32, 4), (4, 32), (32, 2), (16, 16), (8, 8), (4, 4)]
+    for trial in range(40):
+        blocks, metas = [], []
+        for k in range(8):
+            w, h = shapes[int(rng.integers(0, len(shapes)))]
+            chroma = 1 if k == 7 else 0
+            fl = int(rng.integers(0, 4)) | H.TU_SBT_ZERO_OUT
+            c = H.random_block(rng, w, h, density=0.4) if chroma else _sbt_block(rng, w, h, [0.05, 0.4, 1.0][k % 3], big=[0.0, 0.2, 0.6][k % 3])
+            if trial == 0 and not chroma and w == 32:
+                c[:, :] = 0
+                c[0 if h < 32 else min(h, 16) - 1, 15] = -2          # the last position ON the clamp: no terminating prefix bin
+            if chroma:
+                fl &= ~H.TU_SBT_ZERO_OUT                              # (the rig applies SBT to the CU; chroma is untouched by it)
+                want, info = ref.residual_records(c, 1, fl | H.TU_SBT_ZERO_OUT)
+            else:
+                want, info = ref.residual_records(c, 0, fl)
+            got, last, mts = orc.residual_records(c, chroma, fl)
+            assert np.array_equal(got, want), (trial, k, (w, h), chroma, fl)
+            if not chroma:
+                assert bool(info[3]) == mts
+            blocks.append(c)
+            metas.append((w, h, chroma, fl & ~H.TU_SIGN_HIDING))
+        rec = np.concatenate([orc.residual_records(c, m[2], m[3])[0] for c, m in zip(blocks, metas)] + [np.array([0x81FF], np.uint16)])
+        data, _ = orc.encode_records(rec, 30, 2, 3)
+        ref_metas = [(w, h, ch, fl | H.TU_SBT_ZERO_OUT) for (w, h, ch, fl) in metas]   # SBT is a property of the CU in the rig
+        rc_r, got_r, nb_r = ref.residual_decode(data, 30, ref_metas)
+        rc_o, got_o, nb_o = orc.residual_decode(data, 30, metas)
+        assert rc_r == 0 and rc_o == 0 and nb_r == nb_o
+        for k, c in enumerate(blocks):
+            assert np.array_equal(got_o[k], got_r[k]) and np.array_equal(got_o[k], c), (trial, k)
+    # without the flag the same 32-wide block is coded differently (one more prefix bin, the full budget)
+    c = np.zeros((8, 32), np.int32); c[0, 15] = 1
+    assert len(orc.residual_records(c, 0, H.TU_SBT_ZERO_OUT)[0]) < len(orc.residual_records(c, 0, 0)[0])
