@@ -349,7 +349,8 @@ def test_decode_dispatch_on_big_batches(mix):
             c.close()
         finally:
             del os.environ["CABAC_HIP_CHUNKS"]
-        assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"]) and not rd["flags"].any()
+        assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"])
+        assert not rd["flags"][dd["n_records"] > 0].any()      # (the empty substream reports what the oracle reports for it)
         assert np.array_equal(bins, bins_o) and np.array_equal(bins, (records >> 15).astype(np.uint8))
     hip.close()
 
