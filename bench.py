@@ -34,24 +34,29 @@ DESC_BYTES, RESULT_BYTES = 32, 8
 
 def kernel_names(enc_variant, dec_variant, n_sub):
     """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
-    enc = {1: "v1", 2: "v2", 3: "v3", 4: "v4", 5: "v5", 6: "v6", 7: "v7"}.get(enc_variant & 0xFF, "v7" if n_sub >= 3072 else "v6")
-    dec = {1: "v1", 2: "v2", 3: "v3"}.get(dec_variant & 0xFF, "v4")
-    return "encode_kernel_" + enc, "decode_kernel_" + dec
+    enc = {4: "v4", 6: "v6", 7: "v7"}.get(enc_variant & 0xFF, "v7" if n_sub >= 3072 else "v6")
+    return "encode_kernel_" + enc, "decode_kernel_v4"   # (both decode geometries are instances of decode_kernel_v4)
 
 
 def vector_issue(workload, kernel, kernel_ms):
-    """What the kernel does against the roof that binds it: the vector instructions one launch executes
-    (SQ counters of the committed profile run of THIS workload, profiles/r02_sq_instruction_mix.txt) over the chip's vector
-    issue rate, 1024 SIMDs x one wave-wide instruction per ~2 ns (tools/ubench_mix.hip).  None without the profile."""
+    """The vector instructions one launch executes (SQ counters of the committed profile run of THIS workload) against what
+    the vector pipes can take.  Two rates are stated, neither of them a roof this line claims to sit on: the guide's
+    (MI355X_MICROARCH.md, per-instruction cycle constants: a wave-wide VALU instruction every 4 cycles from a lone wave,
+    every 2 once a SIMD holds two or more waves: 1 024 SIMDs x 2.4 GHz / 4 = 614 and / 2 = 1 229 Ginstr/s) and the highest
+    rate THIS instruction mix has been seen to sustain on the chip (16 384 substreams, four waves per SIMD: 4 x 585 M
+    instructions in 4.07 ms = 575 Ginstr/s, profiles/r02_batch_scaling.txt).  None without the profile."""
     if workload != "C4":
         return None
     try:
         for line in open(os.path.join(ROOT, "profiles", "r02_sq_instruction_mix.txt")):
             if line.split("<")[0].strip() == kernel:
                 valu = float(line.split("VALU")[1].split()[0])
-                floor_ms = valu / (1024 * 0.5e9) * 1e3
-                return {"valu_instructions_per_launch": valu, "peak_ginstr_s": 512.0, "floor_ms": round(floor_ms, 4),
-                        "frac": round(floor_ms / kernel_ms, 4), "source": "profiles/r02_sq_instruction_mix.txt (replayed, not live)"}
+                rate = valu / (kernel_ms * 1e-3) / 1e9
+                return {"valu_instructions_per_launch": valu, "achieved_ginstr_s": round(rate, 1),
+                        "peak_ginstr_s": {"lone_wave_per_simd": 614.4, "two_or_more_waves_per_simd": 1228.8},
+                        "frac_of_lone_wave_rate": round(rate / 614.4, 4), "frac_of_nominal_rate": round(rate / 1228.8, 4),
+                        "highest_rate_seen_with_this_mix_ginstr_s": 575.0, "frac_of_highest_seen": round(rate / 575.0, 4),
+                        "source": "profiles/r02_sq_instruction_mix.txt (replayed, not live)"}
     except (OSError, ValueError, IndexError):
         pass
     return None
@@ -78,6 +83,9 @@ def parse_args():
                     help="strong scaling: rank 0 holds ONE batch of the workload, LPT-shards it over the ranks "
                          "(sharding.scatter_substreams over RCCL), every rank codes its shard, the coded bytes are gathered "
                          "back (BASELINE config 5: --workload C5 --strong)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling (the default): every rank codes its own batch of the workload — with --workload C5 that is "
+                         "8 192 substreams per GPU, the multi-GPU case in which every GPU has the parallelism to be busy")
     ap.add_argument("--no-residual", action="store_true", help="skip the residual-binariser leg (C4, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
@@ -571,6 +579,8 @@ def launch_ranks(n):
 
 def main():
     args = parse_args()
+    if args.weak and args.strong:
+        raise SystemExit("--weak and --strong exclude each other")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
@@ -833,6 +843,12 @@ def main():
                              if args.strong else "substreams split across ranks, no data-path collective"),
                 "kernel_variants": {"encode": args.enc_variant, "decode": args.dec_variant},
             },
+            # what this rank's batch offers the chip: the quad decoder puts four substreams in a wave (1 024 SIMDs take one wave
+            # each), the sixteen-per-wave decoder is dispatched from 9 216 about equally long substreams; `equal_substreams` is
+            # the batch's bins over its longest substream's — the number that decides how busy the chip can be kept
+            "occupancy": {"substreams": n_sub, "equal_substreams": round(n_bins / max(int(desc["n_records"].max()), 1), 1),
+                          "quad_decode_waves_per_simd": round(((n_sub + 3) // 4) / 1024.0, 3),
+                          "long_chain_waves_per_simd": round(((n_bins // max(int(desc["n_records"].max()), 1) + 3) // 4) / 1024.0, 3)},
             "encode_mbins_s": round(n_bins / (enc_avg * 1e-3) / 1e6, 2),
             "decode_mbins_s": round(n_bins / (dec_avg * 1e-3) / 1e6, 2),
             "kernel_ms": {"encode": round(enc_avg, 4), "decode": round(dec_avg, 4)},
@@ -841,7 +857,7 @@ def main():
             "hash_whole_batch": whole_hash,
             "roofline": {
                 "bound": "hbm",        # the roof the tier prices against; what limits these kernels is in `limiter`
-                "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD issues one instruction per ~2 ns: ~640 per 16-bin decode step); HBM traffic equals the algorithmic bytes",
+                "limiter": "instruction issue on the serial per-substream chain (one wave per SIMD, one vector instruction per ~2 ns: ~640 per 16-bin decode step for four substreams); HBM traffic equals the algorithmic bytes",
                 "kernel": k_dom,
                 "vector_issue": vector_issue(cfg.name, k_dom, dec_avg if dominant == "decode" else enc_avg),
                 "achieved": round(ach, 3),
