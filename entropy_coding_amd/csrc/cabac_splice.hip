@@ -92,23 +92,22 @@ __global__ __launch_bounds__(256) void splice_plan_kernel(uint32_t n_sub, uint32
   if (bad) atomicOr(err, 1u);
 }
 
-// one workgroup: exclusive scans over the substreams, the totals {records, bytes, error}, every block spliced once
-__global__ __launch_bounds__(1024) void splice_scan_kernel(uint32_t n_sub, uint32_t n_tu, const uint32_t *__restrict__ sub_n,
-                                                           const uint32_t *__restrict__ sub_cap, const uint32_t *__restrict__ seen,
+// every block spliced exactly once (the whole grid looks: one workgroup doing it alone took 0.26 ms for 1.6 M blocks)
+__global__ __launch_bounds__(256) void splice_seen_kernel(uint32_t n_tu, const uint32_t *__restrict__ seen, uint32_t *__restrict__ err) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const bool bad = t < n_tu && seen[t] != 1u;
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(err, 1u);
+}
+
+// one workgroup: exclusive scans over the substreams and the totals {records, bytes, error}
+__global__ __launch_bounds__(1024) void splice_scan_kernel(uint32_t n_sub, const uint32_t *__restrict__ sub_n,
+                                                           const uint32_t *__restrict__ sub_cap,
                                                            uint64_t *__restrict__ rec_base, uint64_t *__restrict__ byte_base,
-                                                           uint32_t *__restrict__ err, uint64_t *__restrict__ totals) {
+                                                           const uint32_t *__restrict__ err, uint64_t *__restrict__ totals) {
   __shared__ uint64_t wave_a[16], wave_b[16];
   __shared__ uint64_t carry_a, carry_b;
-  __shared__ uint32_t any_bad;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0) {
-    carry_a = carry_b = 0;
-    any_bad = 0;
-  }
-  __syncthreads();
-  uint32_t bad = 0;
-  for (uint32_t t = tid; t < n_tu; t += 1024u) bad |= seen[t] != 1u ? 1u : 0u;
-  if (bad) atomicOr(&any_bad, 1u);
+  if (tid == 0) carry_a = carry_b = 0;
   __syncthreads();
   for (uint32_t tile = 0; tile < n_sub; tile += 1024u) {
     const uint32_t s = tile + tid;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(1024) void splice_scan_kernel(uint32_t n_sub, uint3
   if (tid == 0) {
     totals[0] = carry_a;
     totals[1] = carry_b;
-    totals[2] = (any_bad | *err) ? 1u : 0u;
+    totals[2] = *err ? 1u : 0u;
   }
 }
 
@@ -252,7 +251,8 @@ hipError_t launch_splice_plan(hipStream_t st, uint32_t n_sub, uint32_t n_tu, con
   if (n_sub)
     hipLaunchKernelGGL(splice_plan_kernel, dim3(n_sub), dim3(256), 0, st, n_sub, n_tu, desc, splice_first, splices, tu_n_records, pre,
                        sub_n, sub_cap, seen, err);
-  hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, st, n_sub, n_tu, sub_n, sub_cap, seen, rec_base, byte_base, err, totals);
+  if (n_tu) hipLaunchKernelGGL(splice_seen_kernel, dim3((n_tu + 255u) / 256u), dim3(256), 0, st, n_tu, seen, err);
+  hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, st, n_sub, sub_n, sub_cap, rec_base, byte_base, err, totals);
   return hipGetLastError();
 }
 
