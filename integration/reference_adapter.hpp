@@ -47,6 +47,7 @@ public:
     m_blocks.clear();
     EntropyCoding::BinCounter::reset();
     std::fill(m_devCtx.begin(), m_devCtx.end(), 0u);
+    m_BinStore.reset();  // arith_codec.cpp:336
   }
   void finish() override {
     HIPREF_CHECK(!m_Bitstream, "finish() without a bitstream");
@@ -91,6 +92,7 @@ public:
   // scanPosLast | CABAC_TU_INFO_* at flush().
   void spliceResidual(const HipBatch::ResidualBlock &b, std::function<void(uint32_t)> onInfo = nullptr) {
     HIPREF_CHECK(!b.coeff || b.tsFlag, "spliceResidual: code transform_skip_flag with encodeBin first; coefficients required");
+    HIPREF_CHECK(m_BinStore.inUse(), "spliceResidual: the bin store needs the block's bins on the host (ResidualCoderHipRef replays them then)");
     cabac_tu_desc t;
     try {
       t = makeTuDesc(b, 0);
@@ -121,6 +123,7 @@ public:
     HIPREF_CHECK(ctxId >= CABAC_NUM_CONTEXTS, "ctxId out of range");
     EntropyCoding::BinCounter::addCtx(ctxId);
     put(ctxId, bin);
+    m_BinStore.addBin(bin, ctxId);  // arith_codec.cpp:581 (a no-op unless setBinStorage(true))
   }
   void encodeBinEP(unsigned bin) override {
     EntropyCoding::BinCounter::addEP();
@@ -160,12 +163,15 @@ public:
       HIPREF_THROW(e.what());
     }
   }
-  void setBinStorage(bool) override {}
-  const EntropyCoding::BinStore *getBinStore() const override { return nullptr; }
-  // arith_codec.cpp:594-601 hands out a fresh encoder only while the bin store is in use (window-size training); this
-  // encoder keeps no bin store (setBinStorage is a no-op, getBinStore() is null), so there is none to hand out — the
-  // reference's own answer for m_BinStore.inUse() == false
-  EntropyCoding::BinEncIf *getTestBinEncoder() const override { return nullptr; }
+  // The bin store of the window-size training path (arith_codec.cpp:585-601, the reference's own BinStore class): the bins are
+  // all here on the host as they are recorded, so the store is kept exactly as TBinEncoder keeps it.  While it is in use
+  // residual blocks must be binarised where their bins can be stored: spliceResidual refuses, ResidualCoderHipRef replays.
+  void setBinStorage(bool b) override { m_BinStore.setUse(b); }
+  const EntropyCoding::BinStore *getBinStore() const override { return &m_BinStore; }
+  EntropyCoding::BinEncIf *getTestBinEncoder() const override {
+    return m_BinStore.inUse() ? new BinEncoderHipRef(m_batch, Immediate) : nullptr;  // a fresh encoder, as :594-601; Immediate: it is asked getNumWrittenBits()
+  }
+  bool binStoreInUse() const { return m_BinStore.inUse(); }
 
   const EntropyCodingAMD::RecordVector &records() const { return m_records; }
 
@@ -179,6 +185,7 @@ private:
   std::vector<cabac_tu_desc> m_blocks;
   std::vector<std::function<void(uint32_t)>> m_blockInfo;
   std::vector<uint32_t> m_devCtx = std::vector<uint32_t>(CABAC_NUM_CONTEXTS, 0u);
+  EntropyCoding::BinStore m_BinStore;
   int m_qp = 0, m_initId = 0;
 };
 
@@ -275,13 +282,13 @@ public:
     it.depQuant = tu.cs->slice->getDepQuantEnabledFlag();
     it.signHiding = tu.cs->slice->getSignDataHidingEnabledFlag();
     it.maxLog2 = sps.getMaxLog2TrDynamicRange(toChannelType(compID));
-    if (m_hip) return splice(tu, compID, it);
-    m_items.push_back(std::move(it));
+    if (m_hip && !m_hip->binStoreInUse()) return splice(tu, compID, it);
+    m_items.push_back(std::move(it));   // (with the bin store in use the bins are replayed into the encoder, which stores them)
   }
 
   void flush() {
     using namespace Common;
-    if (m_hip) return;  // spliced blocks are coded by HipBatch::flush() with their substream
+    if (m_items.empty()) return;  // spliced blocks are coded by HipBatch::flush() with their substream
     std::vector<HipBatch::ResidualBlock> blocks;
     for (const Item &it : m_items) {
       HipBatch::ResidualBlock b;

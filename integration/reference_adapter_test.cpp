@@ -141,6 +141,44 @@ long adapter_num_written_bits(int which, const uint32_t *ops, long n_ops, int qp
   }
 }
 
+// CPU only: the bin store of the window-size training path (arith_codec.cpp:585-601) under the reference's CABACWriter: with
+// setBinStorage(true) BinEncoder_Std (which 0) and BinEncoderHipRef (which 1) must hold the same bins per context, and
+// getTestBinEncoder() a fresh encoder.  out[ctx] = a digest of that context's bin vector (length * 2654435761 + bits folded).
+long adapter_bin_store(int which, const uint32_t *ops, long n_ops, uint32_t *out, int *has_test_encoder) {
+  try {
+    EntropyCodingAMD::HipBatch batch(0);
+    BinEncoder_Std std_enc;
+    EntropyCodingAMD::BinEncoderHipRef hip_enc(batch);
+    BinEncIf &e = which == 0 ? static_cast<BinEncIf &>(std_enc) : static_cast<BinEncIf &>(hip_enc);
+    OutputBitstream bs;
+    CABACWriter w(e);
+    w.initBitstream(&bs);
+    e.setBinStorage(true);
+    e.reset(30, 2);
+    drive(w, e, ops, n_ops);
+    const BinStore *store = e.getBinStore();
+    if (!store || !store->inUse()) return -4;
+    long total = 0;
+    for (unsigned c = 0; c < Ctx::NumberOfContexts; c++) {
+      const std::vector<bool> &v = store->getBinVector(c);
+      uint32_t h = uint32_t(v.size()) * 2654435761u;
+      for (size_t i = 0; i < v.size(); i++) h = (h << 1 | h >> 31) ^ (v[i] ? 0x9E3779B9u : 0x7F4A7C15u);
+      out[c] = h;
+      total += long(v.size());
+    }
+    BinEncIf *t = e.getTestBinEncoder();
+    *has_test_encoder = t != nullptr;
+    delete t;
+    e.setBinStorage(false);
+    BinEncIf *none = e.getTestBinEncoder();
+    if (none) { delete none; return -5; }
+    return total;
+  } catch (std::exception &ex) {
+    strncpy(g_err, ex.what(), sizeof g_err - 1);
+    return -1;
+  }
+}
+
 // CPU only: what the adapter recorded under the reference's CABACWriter
 long adapter_record(const uint32_t *ops, long n_ops, uint16_t *rec, long cap, uint32_t *numBins) {
   try {

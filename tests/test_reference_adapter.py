@@ -67,6 +67,24 @@ def test_adapter_records_under_reference_cabacwriter(adp):
     assert np.array_equal(rec[:n], orc.ops_to_records(ops)) and nb.value == n
 
 
+def test_bin_store_is_kept_as_the_reference_keeps_it(adp):
+    """CPU: setBinStorage(true) / getBinStore() / getTestBinEncoder() (arith_codec.cpp:585-601, the window-size training
+    path): the recording encoder keeps the reference's own BinStore filled bin for bin as TBinEncoder does."""
+    rng = np.random.default_rng(55)
+    ops = H.random_ops(rng, 5000, ctx_frac=0.7, end_trm=False)
+    f = adp.adapter_bin_store
+    f.restype = ctypes.c_long
+    f.argtypes = [ctypes.c_int, H.u32p, ctypes.c_long, H.u32p, ctypes.POINTER(ctypes.c_int)]
+    got = []
+    for which in (0, 1):
+        out = np.zeros(H.NUM_CTX, np.uint32)
+        has = ctypes.c_int(0)
+        n = f(which, H._ptr(ops, H.u32p), len(ops), H._ptr(out, H.u32p), ctypes.byref(has))
+        assert n > 1000 and has.value == 1, (n, adp.adapter_last_error())
+        got.append((n, out))
+    assert got[0][0] == got[1][0] and np.array_equal(got[0][1], got[1][1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(4))
 def test_reference_cabacwriter_on_gpu_encoder_is_bit_exact(adp, seed):
