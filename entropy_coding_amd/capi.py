@@ -186,7 +186,8 @@ def encode_bound(n_ctx, n_ep, n_trm):
 
 
 class CabacHip:
-    """One codec context = one device + one HIP stream.  Raises if there is no GPU (no CPU fallback)."""
+    """One codec context = one device + one HIP stream (stream=None: a non-blocking stream of the ctx's own; otherwise the
+    caller's stream handle, 0 being the device's default stream).  Raises if there is no GPU (no CPU fallback)."""
 
     def __init__(self, device=0, stream=None):
         self.L = load_library()
@@ -198,7 +199,9 @@ class CabacHip:
         self.device = device
         _live.add(self)
         if stream is not None:
-            self._check(self.L.cabac_hip_set_stream(self.h, vp(stream)))
+            # a HIP stream handle; 0 is the device's default stream (torch's current stream unless it was changed), which the
+            # C ABI takes as CABAC_HIP_STREAM_DEFAULT — a null pointer there means "the ctx's own stream"
+            self._check(self.L.cabac_hip_set_stream(self.h, vp(stream if stream else 1)))
 
     def close(self):
         if getattr(self, "h", None):

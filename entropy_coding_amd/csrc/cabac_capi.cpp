@@ -182,7 +182,8 @@ bool host_is_pinned(const void *p, size_t bytes) {
 // host-pointer call must leave behind when it returns early (the blocks' destinations point into the caller's buffers,
 // which the caller may free as soon as the call has returned — they are dropped, not copied).
 void pipe_quiesce(cabac_hip_ctx *c) {
-  for (hipStream_t st : {c->stream, c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
+  (void)hipStreamSynchronize(c->stream);  // null = the adopted default stream: synchronised like any other
+  for (hipStream_t st : {c->s_in, c->s_out, c->s_k[0], c->s_k[1], c->s_k[2], c->s_k[3]})
     if (st) (void)hipStreamSynchronize(st);
   for (cabac_hip_ctx::Bounce *b : {&c->bounce_in, &c->bounce_out})
     for (int i = 0; i < cabac_hip_ctx::kBounceDepth; i++) {
@@ -459,7 +460,9 @@ int cabac_hip_set_stream(cabac_hip_ctx *c, void *hip_stream) {
     c->own_stream = false;
     c->stream = nullptr;
   }
-  if (hip_stream) {
+  if (hip_stream == CABAC_HIP_STREAM_DEFAULT) {
+    c->stream = nullptr;  // the device's default stream (every launch, event and wait below takes a null stream as that)
+  } else if (hip_stream) {
     c->stream = (hipStream_t)hip_stream;
   } else {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

@@ -125,6 +125,7 @@ def pack_shard(desc, records, idxs):
         ln = torch.from_numpy(lens.astype(np.int32)).to(dev)
         hip = _gather_ctx(dev.index if dev.index is not None else torch.cuda.current_device())
         hip.gather_records_device(len(idxs), src.data_ptr(), dst.data_ptr(), ln.data_ptr(), records.data_ptr(), recs.data_ptr())
+        hip.synchronize()   # src / dst / ln are this function's: they must outlive the launch whatever stream it ran on
         return sub, recs, int(((caps + 15) // 16 * 16).sum())
     pieces = [records[int(desc["rec_offset"][i]):int(desc["rec_offset"][i]) + int(desc["n_records"][i])] for i in idxs]
     if isinstance(records, torch.Tensor):

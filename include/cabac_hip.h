@@ -171,7 +171,11 @@ const char *cabac_hip_last_error(const cabac_hip_ctx *ctx);
  * and return when the results are in the caller's memory.
  *
  * Adopt an existing HIP stream (hipStream_t passed as void*; NULL = back to a stream of the ctx's own).  The stream stays the
- * caller's: it must outlive the ctx's use of it and is not destroyed by cabac_hip_destroy.                              */
+ * caller's: it must outlive the ctx's use of it and is not destroyed by cabac_hip_destroy.
+ * The device's DEFAULT (null) stream — whose handle is the null pointer, which here means "the ctx's own" — is adopted by
+ * passing CABAC_HIP_STREAM_DEFAULT: a caller whose work runs on the default stream (torch's current stream, unless it was
+ * changed, has the handle 0) must pass this and not the handle, or its work and the library's are not ordered at all.   */
+#define CABAC_HIP_STREAM_DEFAULT ((void *)1)
 int cabac_hip_set_stream(cabac_hip_ctx *ctx, void *hip_stream);
 /* hipStreamWaitEvent(ctx stream, event) / hipEventRecord(event, ctx stream); hipEvent_t passed as void*                 */
 int cabac_hip_wait_event(cabac_hip_ctx *ctx, void *hip_event);

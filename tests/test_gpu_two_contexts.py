@@ -59,6 +59,40 @@ def test_encode_beside_decode_on_two_streams(n_sub, top):
     h_dec.close()
 
 
+@pytest.mark.gpu
+def test_default_stream_is_adopted_not_replaced():
+    """cabac_hip.h, stream ordering contract, form (a) on the device's DEFAULT stream: torch's current stream has the handle 0,
+    which the C ABI would read as "the ctx's own stream" — capi passes CABAC_HIP_STREAM_DEFAULT for it.  With the ctx really
+    on that stream a long fill in front of the launch and the read behind it need neither events nor a host synchronisation;
+    on a stream of its own (what a handle of 0 silently gave before) the encoder would run beside the fills."""
+    import torch
+    assert torch.cuda.current_stream().cuda_stream == 0
+    orc = H.load_oracle()
+    rng = np.random.default_rng(98)
+    desc, records, total = _batch(rng, 1500, 2500)
+    want_bytes, want_res = orc.encode_batch(desc, records, total)
+    hip = H.gpu_ctx()
+    src_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).cuda()
+    src_rec = torch.from_numpy(records.view(np.int16).copy()).cuda()
+    for _ in range(3):
+        big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        big.fill_(0xA5)                          # a long fill in front, then the operands are produced ON the stream
+        t_desc, t_rec = torch.zeros_like(src_desc), torch.zeros_like(src_rec)
+        t_desc.copy_(src_desc), t_rec.copy_(src_rec)
+        out = torch.full((total,), 0x5A, dtype=torch.uint8, device="cuda")
+        res = torch.zeros(2 * len(desc), dtype=torch.int32, device="cuda")
+        hip.encode_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), out.data_ptr(), res.data_ptr())
+        got = res.cpu().numpy().view(H.RESULT_DTYPE)
+        host = out.cpu().numpy()
+        assert np.array_equal(got["n_bits"], want_res["n_bits"]) and not got["flags"].any()
+        for s in range(0, len(desc), 3):
+            o, nb = int(desc["byte_offset"][s]), (int(want_res["n_bits"][s]) + 7) // 8
+            assert np.array_equal(host[o:o + nb], want_bytes[o:o + nb]), s
+        del big, t_desc, t_rec
+    hip.close()
+
+
+@pytest.mark.gpu
 def test_own_stream_ordered_with_events():
     """cabac_hip.h, stream ordering contract, form (b): the ctx keeps its own (non-blocking) stream; the producer's fills are
     ordered in front of the launch with cabac_hip_wait_event and the consumer's reads behind it with cabac_hip_record_event —
