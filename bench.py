@@ -48,7 +48,8 @@ def vector_issue(workload, kernel, kernel_ms):
     if workload != "C4":
         return None
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r02_sq_instruction_mix.txt")):
+        name = next(n for n in ("r03_sq_instruction_mix.txt", "r02_sq_instruction_mix.txt") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        for line in open(os.path.join(ROOT, "profiles", name)):
             if line.split("<")[0].strip() == kernel:
                 valu = float(line.split("VALU")[1].split()[0])
                 rate = valu / (kernel_ms * 1e-3) / 1e9
@@ -56,8 +57,8 @@ def vector_issue(workload, kernel, kernel_ms):
                         "peak_ginstr_s": {"lone_wave_per_simd": 614.4, "two_or_more_waves_per_simd": 1228.8},
                         "frac_of_lone_wave_rate": round(rate / 614.4, 4), "frac_of_nominal_rate": round(rate / 1228.8, 4),
                         "highest_rate_seen_with_this_mix_ginstr_s": 575.0, "frac_of_highest_seen": round(rate / 575.0, 4),
-                        "source": "profiles/r02_sq_instruction_mix.txt (replayed, not live)"}
-    except (OSError, ValueError, IndexError):
+                        "source": "profiles/%s (replayed, not live)" % name}
+    except (OSError, ValueError, IndexError, StopIteration):
         pass
     return None
 
@@ -727,6 +728,14 @@ def main():
             hash_match = hash_match and cat.hexdigest() == gold["concat_md5"]
             total_payload = int(sum(len(s) for s in streams))
             del streams
+        # ... and every substream of every rank's shard against the checker's bytes (the golden md5s cover a sample)
+        whole_hash = whole_batch_hash(desc, t_rec.cpu().numpy().view(np.uint16), res_e, t_bytes.cpu().numpy())
+        if world > 1:
+            t = torch.tensor([whole_hash["substreams"], whole_hash["differ"]], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(t)
+            whole_hash.update(substreams=int(t[0].item()), differ=int(t[1].item()), match=int(t[1].item()) == 0)
+        if rank == 0:
+            hash_match = hash_match and whole_hash["match"]
     elif rank == 0:
         host_bytes = t_bytes.cpu().numpy()
         hash_match = True

@@ -1074,7 +1074,8 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cab
   }
   {  // block records (pass 2), straight into the expanded substreams
     Timed t(c, 5);
-    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, tu_off, d_cnt, d_info, exp_rec, c->d_buf[5]));
+    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, tu_off, d_cnt, d_info, exp_rec, c->d_buf[5],
+                                      /*order_ready=*/true));  // the block order of the sizes pass above: same tus[], same scratch
   }
   {
     Timed t(c, 0);

@@ -44,9 +44,10 @@ hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_of
 // residual binariser (cabac_residual.hip)
 // scratch: residual_scratch_bytes(n_tu) bytes of device memory the launch may overwrite (block ordering)
 size_t residual_scratch_bytes(uint32_t n_tu);
+// order_ready: `scratch` still holds the block order of an earlier launch over the SAME tus[] (the sizes pass of this call)
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
-                           void *scratch);
+                           void *scratch, bool order_ready = false);
 
 // residual parser (cabac_residual.hip): bytes -> coefficient blocks, one substream = blocks [tile_first[s], tile_first[s+1])
 // (cabac_residual_parse.hip); tu_info (may be null): per block scanPosLast | CABAC_TU_INFO_*

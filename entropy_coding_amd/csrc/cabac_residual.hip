@@ -105,12 +105,23 @@ constexpr uint32_t kRowsPerBlock = 16;  // 256 threads
 
 }  // namespace
 
-// log2 of the number of coefficient groups of a block (0..6), 7 for a descriptor the kernel rejects
+// g_log2SbbSize (rom.cpp:41-50): log2 of a coefficient group's width and height for a block of 2^lw x 2^lh
+__device__ __forceinline__ void group_shape(uint32_t lw, uint32_t lh, uint32_t &cgw_l2, uint32_t &cgh_l2) {
+  if (lw == 0u) { cgw_l2 = 0u; cgh_l2 = lh < 4u ? lh : 4u; }
+  else if (lh == 0u) { cgw_l2 = lw < 4u ? lw : 4u; cgh_l2 = 0u; }
+  else if (lw == 1u) { cgw_l2 = 1u; cgh_l2 = lh <= 2u ? 1u : 3u; }
+  else if (lh == 1u) { cgh_l2 = 1u; cgw_l2 = lw <= 2u ? 1u : 3u; }
+  else { cgw_l2 = 2u; cgh_l2 = 2u; }
+}
+
+// log2 of the number of coefficient groups of a block's coded region (0..6), 7 for a descriptor the kernel rejects.
+// Class 0 is exactly "one group": those blocks take the lean walk (residual_rows<.., kSingle>).
 __device__ __forceinline__ uint32_t size_class(const cabac_tu_desc &d) {
   const uint32_t lw = d.log2_width, lh = d.log2_height;
   if (lw > 6u || lh > 6u) return 7u;
-  const uint32_t coded = (lw < 5u ? lw : 5u) + (lh < 5u ? lh : 5u);  // log2 of the coded area
-  return coded > 4u ? coded - 4u : 0u;                               // groups hold 16 (or all, if fewer) coefficients
+  uint32_t cgw_l2, cgh_l2;
+  group_shape(lw, lh, cgw_l2, cgh_l2);
+  return ((lw < 5u ? lw : 5u) - cgw_l2) + ((lh < 5u ? lh : 5u) - cgh_l2);
 }
 
 constexpr uint32_t kClasses = 8;
@@ -248,7 +259,10 @@ __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_
 // Smaller blocks fit a line or two and are read directly.
 // kTs: the transform-skip walk (residual_codingTS) for the blocks flagged CABAC_TU_TRANSFORM_SKIP, which the other
 // variants leave alone: a launch of its own, so that its registers and code do not weigh on the regular walk.
-template <bool kWrite, uint32_t kStageDw, bool kTs>
+// kSingle: every block of the workgroup is ONE coefficient group (class 0: 4 x 4 and smaller, 2 x 8, 1 x 16): no group
+// scan, no group flags, the coefficient is loaded once, and the template of a position never leaves the block — it is read
+// from the row's own lanes (five ds_bpermute of a packed contribution word) instead of five loads.
+template <bool kWrite, uint32_t kStageDw, bool kTs, bool kSingle = false>
 __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage, uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
                                               const int32_t *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
                                               uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
@@ -276,16 +290,12 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   if (bad) lw = lh = chroma = 0;
   live = live && !bad;
   const uint32_t w = 1u << lw, h = 1u << lh;
-  uint32_t cgw_l2, cgh_l2;  // g_log2SbbSize, rom.cpp:41-50
-  if (lw == 0u) { cgw_l2 = 0u; cgh_l2 = lh < 4u ? lh : 4u; }
-  else if (lh == 0u) { cgw_l2 = lw < 4u ? lw : 4u; cgh_l2 = 0u; }
-  else if (lw == 1u) { cgw_l2 = 1u; cgh_l2 = lh <= 2u ? 1u : 3u; }
-  else if (lh == 1u) { cgh_l2 = 1u; cgw_l2 = lw <= 2u ? 1u : 3u; }
-  else { cgw_l2 = 2u; cgh_l2 = 2u; }
+  uint32_t cgw_l2, cgh_l2;
+  group_shape(lw, lh, cgw_l2, cgh_l2);
   const uint32_t cg_l2 = cgw_l2 + cgh_l2, cg_size = 1u << cg_l2;
   const uint32_t we = w < 32u ? w : 32u, he = h < 32u ? h : 32u;
   const uint32_t lwg = (31u - (uint32_t)__builtin_clz(we)) - cgw_l2, lhg = (31u - (uint32_t)__builtin_clz(he)) - cgh_l2;
-  const uint32_t wg = 1u << lwg, hg = 1u << lhg, n_cg = live ? wg * hg : 0u;
+  const uint32_t wg = kSingle ? 1u : 1u << lwg, hg = kSingle ? 1u : 1u << lhg, n_cg = live ? wg * hg : 0u;
   const uint32_t in_cg = c_diag.in_cg[cgw_l2][cgh_l2][l & (cg_size - 1u)];
   const uint32_t ix = in_cg & 15u, iy = in_cg >> 4;
   const uint8_t *grid = c_diag.grid[lwg][lhg];
@@ -321,7 +331,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
   // SBT / MTS zero-out (CABAC_TU_SBT_ZERO_OUT; cabac_writer.cpp:2660-2667, :2507-2516, unit.cpp:465-479): a 32-wide (32-tall)
   // luma block is coded as if only its left (upper) 16 columns (rows) existed
-  const bool zo = !kTs && live && (flags & CABAC_TU_SBT_ZERO_OUT) && chroma == 0u && w <= 32u && h <= 32u;
+  const bool zo = !kTs && !kSingle && live && (flags & CABAC_TU_SBT_ZERO_OUT) && chroma == 0u && w <= 32u && h <= 32u;
   const uint32_t zo_w = (zo && w == 32u) ? 16u : we, zo_h = (zo && h == 32u) ? 16u : he;
   auto zeroed_out = [&](uint32_t gpos) { return (((gpos & 15u) << cgw_l2) >= zo_w) || (((gpos >> 4) << cgh_l2) >= zo_h); };
   uint64_t zo_groups = 0;  // by scan index: groups the walk passes over without a flag
@@ -329,7 +339,16 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   int last = -1;
   uint64_t coded = 0;    // by scan index of the group
   uint64_t sig_map = 0;  // by raster position in the group grid: bit gy * wg + gx
-  {
+  int32_t c_single = 0;  // kSingle: the lane's coefficient, loaded here once
+  if constexpr (kSingle) {
+    if (live && lane_in_cg) c_single = coeff[(iy << lw) + ix];
+    const uint32_t nz = row_bits(c_single != 0, row_shift);
+    if (nz) {
+      last = (int)(31u - (uint32_t)__builtin_clz(nz));
+      coded = 1ull;
+      sig_map = 1ull;
+    }
+  } else {
     int top = (int)n_cg - 1;  // the rows of a wave normally share n_cg (class order)
     top = max(top, __shfl_xor(top, 16));
     top = max(top, __shfl_xor(top, 32));
@@ -365,7 +384,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
   }
   if (!kTs && live) {
     const uint32_t lcg = (uint32_t)last >> cg_l2;
-    const uint32_t lgp = grid[lcg];
+    const uint32_t lgp = kSingle ? 0u : grid[lcg];
     const uint32_t lin = c_diag.in_cg[cgw_l2][cgh_l2][(uint32_t)last & (cg_size - 1u)];
     const uint32_t px = ((lgp & 15u) << cgw_l2) + (lin & 15u), py = ((lgp >> 4) << cgh_l2) + (lin >> 4);
     const uint32_t luma_off_x = lw < 3u ? 0u : lw == 3u ? 3u : lw == 4u ? 6u : lw == 5u ? 10u : 15u;
@@ -396,12 +415,13 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
   while (__ballot(todo != 0ull) != 0ull) {
     const bool row_on = todo != 0ull;
-    const int cg = row_on ? 63 - __builtin_clzll(todo) : 0;
-    todo &= ~(1ull << cg);
+    const int cg = (kSingle || !row_on) ? 0 : 63 - __builtin_clzll(todo);
+    if constexpr (kSingle) todo = 0ull;  // the one group of the block
+    else todo &= ~(1ull << cg);
     // coded_sub_block_flag (cabac_writer.cpp:2733-2743) of the empty groups passed over, then of this group
-    const uint32_t gap = row_on ? (uint32_t)(prev_cg - 1 - cg) : 0u;
+    const uint32_t gap = (kSingle || !row_on) ? 0u : (uint32_t)(prev_cg - 1 - cg);
     uint32_t gap_flags = gap;  // flags actually coded: the zeroed-out groups among those passed over have none
-    if (__ballot(zo && gap != 0u) != 0ull) {
+    if (!kSingle && __ballot(zo && gap != 0u) != 0ull) {
       uint32_t kept = 0;
       for (uint32_t base = 0; __ballot(base < gap) != 0ull; base += 16u) {
         const uint32_t j = base + l;
@@ -419,7 +439,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
       }
       gap_flags = zo ? kept : gap;
     }
-    if (kWrite && __ballot(!zo && gap != 0u) != 0ull) {
+    if (kWrite && !kSingle && __ballot(!zo && gap != 0u) != 0ull) {
       for (uint32_t base = 0; __ballot(!zo && base < gap) != 0ull; base += 16u) {
         const uint32_t j = base + l;
         if (!zo && j < gap) {
@@ -433,7 +453,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     }
     off += gap_flags;
     prev_cg = row_on ? cg : prev_cg;
-    const uint32_t gpos = row_on ? grid[cg] : 0u;
+    const uint32_t gpos = (kSingle || !row_on) ? 0u : grid[cg];
     const uint32_t gx = gpos & 15u, gy = gpos >> 4;
     const uint32_t gbit = gy * wg + gx;
     const bool coded_group = (coded >> cg) & 1ull;
@@ -456,7 +476,8 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
     // the coefficient; its template is fetched below, once it is known that somebody codes this group
     int32_t c = 0;
-    if (in_range) c = coef_at(x, y);
+    if constexpr (kSingle) c = in_range ? c_single : 0;
+    else if (in_range) c = coef_at(x, y);
     const uint32_t a = (uint32_t)(c < 0 ? -c : c);
     const bool nzero = c != 0;
     const uint32_t m_nz = row_bits(nzero, row_shift);
@@ -470,7 +491,25 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
     // budget (at most 64 context bins go per group) may no longer reach.
     int sum_abs = 0, sum_clip = 0, n_tmpl = 0;
     const bool want_tmpl = kWrite || __ballot(act && (a >= 4u || budget < 68)) != 0ull;
-    if (want_tmpl && act) {
+    if constexpr (kSingle) {
+      if (want_tmpl) {  // wave-uniform: every lane takes part in the exchange
+        // this position's contribution to a template that holds it: min(|c|, 63) (what rice_of can tell apart), the clipped
+        // level of sigCtxIdAbs, non-zero — 9 + 5 + 3 bits, wide enough for a sum of five
+        const uint32_t a6 = a < 63u ? a : 63u;
+        const uint32_t mine_word = act ? (a6 | (min(a, 4u + (a & 1u)) << 9) | ((a != 0u ? 1u : 0u) << 14)) : 0u;
+        const uint32_t nb = c_diag.nbr[cgw_l2][cgh_l2][l & (cg_size - 1u)];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 5u; q++) {
+          const uint32_t at = (nb >> (5u * q)) & 31u;
+          const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) | (at & 15u)) << 2), (int)mine_word);
+          sum += at < 16u ? v : 0u;
+        }
+        sum_abs = (int)(sum & 511u);
+        sum_clip = (int)((sum >> 9) & 31u);
+        n_tmpl = (int)(sum >> 14);
+      }
+    } else if (want_tmpl && act) {
       // the coded region is the block, or its top-left 32 x 32: what lies outside is zero by construction of the
       // stream (rom.cpp:218-226) and is not read
       const bool x1 = x + 1u < we, x2 = x + 2u < we, y1 = y + 1u < he, y2 = y + 2u < he;
@@ -734,7 +773,12 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
     for (uint32_t wg = big_wgs + blockIdx.x; wg < big_wgs + mid_wgs; wg += gridDim.x)
       residual_rows<kWrite, 256u, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   } else if (blockIdx.x >= big_wgs + mid_wgs) {
-    residual_rows<kWrite, 0u, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+    // class 0 — one group per block — comes last in the order and takes the lean walk
+    const uint32_t single_from = big_wgs + mid_wgs + (((class_count[3] + r) & ~r) + ((class_count[2] + r) & ~r) + ((class_count[1] + r) & ~r)) / kRowsPerBlock;
+    if (blockIdx.x >= single_from)
+      residual_rows<kWrite, 0u, false, true>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+    else
+      residual_rows<kWrite, 0u, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   }
 }
 
@@ -759,14 +803,34 @@ size_t residual_scratch_bytes(uint32_t n_tu) {
   return sizeof(uint32_t) * (kScratchHeader + (size_t)n_tu + kClasses * kRowsPerBlock);
 }
 
+template <bool kWrite>
+static hipError_t launch_residual_passes(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+                                         const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
+                                         uint32_t *s32, uint32_t rows) {
+  // (The three launches side by side on three streams, the staged ones holding few waves per CU, were measured: 1.53 ms
+  // against 1.45 one after the other for the records pass — each of them is bound by instruction issue, not by occupancy.)
+  const dim3 grid(rows / kRowsPerBlock);
+  const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u), grid_mid(grid.x < 8192u ? grid.x : 8192u);
+  const uint32_t *order = s32 + kScratchHeader;
+  hipLaunchKernelGGL((residual_kernel<kWrite, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                     records, order, s32);
+  hipLaunchKernelGGL((residual_kernel<kWrite, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                     records, order, s32);
+  hipLaunchKernelGGL((residual_kernel<kWrite, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+                     records, order, s32);
+  hipLaunchKernelGGL((residual_ts_kernel<kWrite>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
+                     info, records, order, s32);
+  return hipGetLastError();
+}
+
 hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
-                           void *scratch) {
+                           void *scratch, bool order_ready) {
   if (n_tu == 0) return hipSuccess;
   // blocks ordered by group count: [counts | cursors | permutation, 0xFFFFFFFF where a class is padded to 16 rows]
   uint32_t *s32 = static_cast<uint32_t *>(scratch);
   const uint32_t rows = n_tu + kClasses * kRowsPerBlock;  // upper bound of the padded list
-  {  // any complete permutation of the n_tu blocks is correct; this one balances the waves
+  if (!order_ready) {  // any complete permutation of the n_tu blocks is correct; this one balances the waves
     hipError_t e = hipMemsetAsync(s32, 0, sizeof(uint32_t) * kScratchHeader, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(s32 + kScratchHeader, 0xff, sizeof(uint32_t) * rows, st);
@@ -775,29 +839,8 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
     hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
     hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
   }
-  const dim3 grid(rows / kRowsPerBlock);
-  const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u), grid_mid(grid.x < 8192u ? grid.x : 8192u);
-  const uint32_t *order = s32 + kScratchHeader;
-  if (records) {
-    hipLaunchKernelGGL((residual_kernel<true, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<true, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<true, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_ts_kernel<true>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
-                       info, records, order, s32);
-  } else {
-    hipLaunchKernelGGL((residual_kernel<false, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<false, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_kernel<false, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
-                       records, order, s32);
-    hipLaunchKernelGGL((residual_ts_kernel<false>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
-                       info, records, order, s32);
-  }
-  return hipGetLastError();
+  return records ? launch_residual_passes<true>(st, n_tu, tus, coeff, rec_offset, n_records, info, records, s32, rows)
+                 : launch_residual_passes<false>(st, n_tu, tus, coeff, rec_offset, n_records, info, records, s32, rows);
 }
 
 }  // namespace cabac

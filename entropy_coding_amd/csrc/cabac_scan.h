@@ -13,6 +13,9 @@ namespace {
 struct DiagLut {
   uint8_t grid[4][4][64];   // [log2 groups per row][log2 groups per column][group index]
   uint8_t in_cg[5][5][16];  // [log2 group width][log2 group height][position in group]
+  // the five template neighbours (x+1,y) (x+2,y) (x+1,y+1) (x,y+1) (x,y+2) of a position as positions of the SAME group,
+  // 5 bits each, 31 = outside the group: for blocks that are one group (the template never leaves the block's lanes)
+  uint32_t nbr[5][5][16];
 };
 
 constexpr void fill_diag(uint8_t *out, int bw, int bh) {
@@ -30,6 +33,23 @@ constexpr DiagLut make_lut() {
     for (int b = 0; b < 4; b++) fill_diag(t.grid[a][b], 1 << a, 1 << b);
   for (int a = 0; a < 5; a++)
     for (int b = 0; b + a < 5; b++) fill_diag(t.in_cg[a][b], 1 << a, 1 << b);
+  for (int a = 0; a < 5; a++)
+    for (int b = 0; b + a < 5; b++) {
+      const int n = 1 << (a + b);
+      for (int k = 0; k < n; k++) {
+        const int x = t.in_cg[a][b][k] & 15, y = t.in_cg[a][b][k] >> 4;
+        const int nx[5] = {x + 1, x + 2, x + 1, x, x}, ny[5] = {y, y, y + 1, y + 1, y + 2};
+        uint32_t word = 0;
+        for (int q = 0; q < 5; q++) {
+          uint32_t at = 31;
+          if (nx[q] < (1 << a) && ny[q] < (1 << b))
+            for (int m = 0; m < n; m++)
+              if ((t.in_cg[a][b][m] & 15) == nx[q] && (t.in_cg[a][b][m] >> 4) == ny[q]) at = (uint32_t)m;
+          word |= at << (5 * q);
+        }
+        t.nbr[a][b][k] = word;
+      }
+    }
   return t;
 }
 

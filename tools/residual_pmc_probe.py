@@ -26,5 +26,15 @@ for (w, h) in [(4, 4), (8, 8), (16, 8), (16, 16), (32, 32)]:
     torch.cuda.synchronize()
     hip.residual_device(len(all_tus), t_tu.data_ptr(), t_co.data_ptr(), 0, t_cnt.data_ptr(), 0, 0)
     hip.synchronize()
+    if os.environ.get("PROBE_RECORDS") == "1":   # ... and the records pass (tools/residual_pmc_records.sh)
+        cnt = t_cnt.to(torch.int64)
+        t_off = torch.cumsum(cnt, 0) - cnt
+        n_rec = int(cnt.sum().item())
+        t_rec = torch.zeros(n_rec + 64, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        hip.residual_device(len(all_tus), t_tu.data_ptr(), t_co.data_ptr(), t_off.data_ptr(), t_cnt.data_ptr(), 0, t_rec.data_ptr())
+        hip.synchronize()
+        print("shape %dx%d: records pass wrote %d records = %d KiB" % (w, h, n_rec, n_rec * 2 >> 10), flush=True)
+        del t_rec, t_off, cnt
     print("shape %dx%d: %d blocks, %d KiB of coefficients, %d KiB of descriptors" % (w, h, len(all_tus), total * 4 >> 10, len(all_tus) * 16 >> 10), flush=True)
 hip.close()
