@@ -736,18 +736,24 @@ def main():
             whole_hash.update(substreams=int(t[0].item()), differ=int(t[1].item()), match=int(t[1].item()) == 0)
         if rank == 0:
             hash_match = hash_match and whole_hash["match"]
-    elif rank == 0:
+    else:
         host_bytes = t_bytes.cpu().numpy()
-        hash_match = True
-        row_of = {int(idx): k for k, idx in enumerate(order)}
-        for g in gold["substreams"]:
-            s = row_of.get(g["index"])
-            if s is not None:
-                o, nb = int(desc["byte_offset"][s]), (int(res_e["n_bits"][s]) + 7) // 8
-                hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
-        # ... and every substream of the batch against the checker's bytes (the golden md5s above cover a sample)
+        if rank == 0:
+            hash_match = True
+            row_of = {int(idx): k for k, idx in enumerate(order)}
+            for g in gold["substreams"]:
+                s = row_of.get(g["index"])
+                if s is not None:
+                    o, nb = int(desc["byte_offset"][s]), (int(res_e["n_bits"][s]) + 7) // 8
+                    hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
+        # ... and every substream of every rank's batch against the checker's bytes (the golden md5s above cover a sample)
         whole_hash = whole_batch_hash(desc, records, res_e, host_bytes)
-        hash_match = hash_match and whole_hash["match"]
+        if world > 1:
+            t = torch.tensor([whole_hash["substreams"], whole_hash["differ"]], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(t)
+            whole_hash.update(substreams=int(t[0].item()), differ=int(t[1].item()), match=int(t[1].item()) == 0)
+        if rank == 0:
+            hash_match = hash_match and whole_hash["match"]
         del host_bytes
 
     # ---- bit estimator on the same resident records, outside the timed region ----

@@ -334,7 +334,11 @@ __device__ __forceinline__ int32_t blk_val(const int32_t *blk, const BlockGeom &
 __device__ __forceinline__ uint32_t sig_set_base(uint32_t set) { return (uint32_t)((0x8E827A6E665Aull >> (8u * set)) & 0xffu); }
 
 // ---- regular residual coding: one block (after ts_flag) -----------------------------------------------------------
-template <class D>
+// kZo: the block is coded with the SBT / MTS zero-out.  A variant of its own, because its three extra scalars (the reduced
+// extents and the flag) are live across the whole walk: compiled into the common walk they push it over the scalar register
+// file and hipcc moves uniform values of the chain to vector registers (static count 1 842 -> 2 340 vector instructions,
+// 5.91 -> 6.13 ms on the bench's tiles, none of which uses the zero-out).
+template <class D, bool kZo>
 __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk, const LdsTables &tab, const BlockGeom &g,
                                                   uint32_t lane) {
   const uint32_t chroma = g.chroma, j = lane & 15u;
@@ -345,8 +349,7 @@ __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk
   const uint32_t off_x = chroma ? 0u : luma_off_x, off_y = chroma ? 0u : luma_off_y;
   const uint32_t sh_x = chroma ? min((1u << g.lw) >> 3, 2u) : (g.lw + 1u) >> 2, sh_y = chroma ? min((1u << g.lh) >> 3, 2u) : (g.lh + 1u) >> 2;
   // SBT / MTS zero-out (CABAC_TU_SBT_ZERO_OUT; cabac_reader.cpp:2880-2891, :2718-2727, unit.cpp:465-479)
-  const bool zo = (g.fl & CABAC_TU_SBT_ZERO_OUT) && chroma == 0u && g.lw <= 5u && g.lh <= 5u;
-  const uint32_t zo_w = (zo && g.lw == 5u) ? 16u : g.we, zo_h = (zo && g.lh == 5u) ? 16u : g.he;
+  const uint32_t zo_w = (kZo && g.lw == 5u) ? 16u : g.we, zo_h = (kZo && g.lh == 5u) ? 16u : g.he;
   const uint32_t max_x = group_idx(zo_w - 1u), max_y = group_idx(zo_h - 1u);
   uint32_t px = 0, py = 0;
   for (; px < max_x; px++) {
@@ -390,7 +393,7 @@ __device__ __forceinline__ uint32_t parse_regular(D &d, uint4 *ctx, int32_t *blk
   for (int32_t cg = (int32_t)last_cg; cg >= 0; cg--) {
     PP_TICK(c0);
     const uint32_t gp = rl(gl, (uint32_t)cg), gx = gp & 15u, gy = gp >> 4, gbit = gy * g.wg + gx;
-    if ((gx << g.cgw_l2) >= zo_w || (gy << g.cgh_l2) >= zo_h) continue;  // zeroed out: nothing is coded for this group
+    if (kZo && ((gx << g.cgw_l2) >= zo_w || (gy << g.cgh_l2) >= zo_h)) continue;  // zeroed out: nothing is coded for this group
     bool sig = cg == (int32_t)last_cg || cg == 0;
     if (!sig) {  // coded_sub_block_flag (cabac_reader.cpp:2965-2975)
       const uint32_t right = gx + 1u < g.wg ? (uint32_t)(sig_map >> (gbit + 1u)) & 1u : 0u;
@@ -752,7 +755,8 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     PP_TICK(b1);
     PP_ADD(0, b0, b1);
     if (ts) parse_ts(d, ctx, blk, tab, g, lane);
-    else info = parse_regular(d, ctx, blk, tab, g, lane);
+    else if ((g.fl & CABAC_TU_SBT_ZERO_OUT) && g.chroma == 0u && g.lw <= 5u && g.lh <= 5u) info = parse_regular<decltype(d), true>(d, ctx, blk, tab, g, lane);
+    else info = parse_regular<decltype(d), false>(d, ctx, blk, tab, g, lane);
     if (tu_info && lane == 0u) tu_info[t] = info;
     PP_TICK(b2);
     // the finished block goes out row by row (all lanes), the LDS copy is cleared for the next block

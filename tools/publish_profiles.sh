@@ -7,7 +7,7 @@ F=gpurun_out/final_$TAG
 for f in batch_scaling e2e_chunks pcie_probe enc_scaling; do
   [ -f $F/$f.txt ] && grep -v amdgpu.ids $F/$f.txt > profiles/${R}_$f.txt
 done
-for w in C2 C3 C4 C5 C5_strong_1gpu C4_2rank_rehearsal C3_strong_2rank_rehearsal; do [ -f $F/bench_$w.json ] && cp $F/bench_$w.json profiles/${R}_final_bench_$w.json; done
+for w in C2 C3 C4 C5 C5_strong_1gpu C4_2rank_rehearsal C3_strong_2rank_rehearsal; do [ -f $F/bench_$w.json ] && grep '^{' $F/bench_$w.json > profiles/${R}_final_bench_$w.json; done   # (gloo prints its connection lines to stdout)
 [ -f gpurun_out/sq_mix/mix.txt ] && cp gpurun_out/sq_mix/mix.txt profiles/${R}_sq_instruction_mix.txt
 [ -f gpurun_out/pmc_records/records.txt ] && cat gpurun_out/pmc_records/records.txt gpurun_out/pmc_records/probe.log | grep -v amdgpu.ids > profiles/${R}_residual_pmc_records_pass.txt
 [ -f gpurun_out/${R}_exp_residual.txt ] && cp gpurun_out/${R}_exp_residual.txt profiles/${R}_exp_residual.txt
