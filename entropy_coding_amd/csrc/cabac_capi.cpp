@@ -1056,7 +1056,7 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cab
   }
   {
     Timed t(c, 10);
-    HIP_TRY(c, cabac::launch_splice_plan(c->stream, n_sub, n_tu, d_desc, d_splice_first, d_splices, d_cnt, pre, sub_n, sub_cap, seen, err,
+    HIP_TRY(c, cabac::launch_splice_plan(c->stream, n_sub, n_tu, d_desc, d_splice_first, d_splices, n_splice, d_cnt, pre, sub_n, sub_cap, seen, err,
                                          rec_base, byte_base, totals));
   }
   uint64_t *h_tot = static_cast<uint64_t *>(c->h_totals);

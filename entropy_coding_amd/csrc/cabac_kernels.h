@@ -58,9 +58,9 @@ hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_sub
 // residual records spliced into host-recorded substreams (cabac_splice.hip); array sizes: pre n_splice + n_sub + 1,
 // sub_n / sub_cap / rec_base / byte_base n_sub, seen n_tu, err 1, totals 3 ({records, bytes, error})
 hipError_t launch_splice_plan(hipStream_t st, uint32_t n_sub, uint32_t n_tu, const cabac_substream_desc *desc,
-                              const uint32_t *splice_first, const cabac_splice *splices, const uint32_t *tu_n_records,
-                              uint32_t *pre, uint32_t *sub_n, uint32_t *sub_cap, uint32_t *seen, uint32_t *err, uint64_t *rec_base,
-                              uint64_t *byte_base, uint64_t *totals);
+                              const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_splice,
+                              const uint32_t *tu_n_records, uint32_t *pre, uint32_t *sub_n, uint32_t *sub_cap, uint32_t *seen, uint32_t *err,
+                              uint64_t *rec_base, uint64_t *byte_base, uint64_t *totals);
 hipError_t launch_splice_expand(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *host_records,
                                 const uint32_t *splice_first, const cabac_splice *splices, const uint32_t *pre,
                                 const uint32_t *sub_n, const uint32_t *sub_cap, const uint64_t *rec_base, const uint64_t *byte_base,

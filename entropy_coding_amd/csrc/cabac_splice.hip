@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t slot_bytes(uint64_t n_records) { return ((7u
 }  // namespace
 
 // pre[j + s] = records of the substream's blocks spliced in before splice j (pre[j1 + s] = of all of them)
-__global__ __launch_bounds__(256) void splice_plan_kernel(uint32_t n_sub, uint32_t n_tu, const cabac_substream_desc *__restrict__ desc,
+__global__ __launch_bounds__(256) void splice_plan_kernel(uint32_t n_sub, uint32_t n_tu, uint32_t n_splice, const cabac_substream_desc *__restrict__ desc,
                                                           const uint32_t *__restrict__ splice_first,
                                                           const cabac_splice *__restrict__ splices,
                                                           const uint32_t *__restrict__ tu_n_records, uint32_t *__restrict__ pre,
@@ -59,10 +59,12 @@ __global__ __launch_bounds__(256) void splice_plan_kernel(uint32_t n_sub, uint32
   __shared__ uint64_t wave_sum[4];
   const uint32_t s = blockIdx.x;
   if (s >= n_sub) return;
-  const uint32_t j0 = splice_first[s], j1 = splice_first[s + 1];
+  uint32_t j0 = splice_first[s], j1 = splice_first[s + 1];
   const uint32_t n_host = desc[s].n_records;
   uint64_t carry = 0;
-  uint32_t bad = j1 < j0 ? 1u : 0u;
+  // a list that is not one: nothing of it is read (the arrays hold n_splice splices and n_splice + n_sub + 1 sums)
+  uint32_t bad = (j1 < j0 || j1 > n_splice || (s == 0u && j0 != 0u) || (s + 1u == n_sub && j1 != n_splice)) ? 1u : 0u;
+  if (bad) j0 = j1 = 0u;
   for (uint32_t base = j0; base < j1; base += 256u) {
     const uint32_t j = base + threadIdx.x;
     const bool valid = j < j1;
@@ -241,16 +243,16 @@ hipError_t launch_tu_info_any(hipStream_t st, uint32_t n_tu, const uint32_t *inf
 }
 
 hipError_t launch_splice_plan(hipStream_t st, uint32_t n_sub, uint32_t n_tu, const cabac_substream_desc *desc,
-                              const uint32_t *splice_first, const cabac_splice *splices, const uint32_t *tu_n_records,
-                              uint32_t *pre, uint32_t *sub_n, uint32_t *sub_cap, uint32_t *seen, uint32_t *err, uint64_t *rec_base,
-                              uint64_t *byte_base, uint64_t *totals) {
+                              const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_splice,
+                              const uint32_t *tu_n_records, uint32_t *pre, uint32_t *sub_n, uint32_t *sub_cap, uint32_t *seen, uint32_t *err,
+                              uint64_t *rec_base, uint64_t *byte_base, uint64_t *totals) {
   hipError_t e = hipMemsetAsync(seen, 0, sizeof(uint32_t) * (n_tu ? n_tu : 1u), st);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(err, 0, sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   if (n_sub)
-    hipLaunchKernelGGL(splice_plan_kernel, dim3(n_sub), dim3(256), 0, st, n_sub, n_tu, desc, splice_first, splices, tu_n_records, pre,
-                       sub_n, sub_cap, seen, err);
+    hipLaunchKernelGGL(splice_plan_kernel, dim3(n_sub), dim3(256), 0, st, n_sub, n_tu, n_splice, desc, splice_first, splices, tu_n_records,
+                       pre, sub_n, sub_cap, seen, err);
   if (n_tu) hipLaunchKernelGGL(splice_seen_kernel, dim3((n_tu + 255u) / 256u), dim3(256), 0, st, n_tu, seen, err);
   hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, st, n_sub, sub_n, sub_cap, rec_base, byte_base, err, totals);
   return hipGetLastError();

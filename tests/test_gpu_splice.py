@@ -151,6 +151,18 @@ def test_spliced_residual_device_pointers_through_every_encoder():
         cnt = t_cnt.cpu().numpy().view(np.uint32).reshape(len(desc), -1)
         assert np.array_equal(cnt[7], counts_of(expanded[7]))
         hip.close()
+    # a splice_first[] on the device that is not a partition of the splice list (the device form cannot look at it on the host):
+    # refused by the plan kernel without reading anything through it
+    hip = H.gpu_ctx()
+    for wrong in (first[::-1].copy(), np.where(np.arange(len(first)) == len(first) // 2, 1 << 30, first).astype(np.uint32),
+                  (first + 1).astype(np.uint32)):
+        t_wrong = dev(wrong, np.int32)
+        with pytest.raises(capi.CabacHipError) as e:
+            hip.encode_residual_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), t_wrong.data_ptr(), t_sp.data_ptr(), len(splices),
+                                       len(tus), t_tu.data_ptr(), t_co.data_ptr(), t_pay.data_ptr(), total + 64, t_off.data_ptr(),
+                                       t_res.data_ptr(), 0, 0)
+        assert "splice list" in str(e.value)
+    hip.close()
 
 
 def test_spliced_residual_rejects_bad_splice_lists():
