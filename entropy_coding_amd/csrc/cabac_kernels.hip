@@ -61,18 +61,20 @@ hipError_t launch_encode(hipStream_t st, int variant, uint32_t n_sub, const caba
   return hipErrorInvalidValue;
 }
 
-// variant: 0 = auto, 4 = quad decoder (four substreams per wave), 8 = sixteen substreams per wave (big batches); anything else is refused
+// variant: 0 = auto, 4 = quad decoder (four substreams per wave), 8 = sixteen substreams per wave (big batches), 1 = one substream per
+// wave (few substreams); anything else is refused
 hipError_t launch_decode(hipStream_t st, int variant, uint32_t n_sub, const cabac_substream_desc *desc,
                          const uint16_t *records, const uint8_t *bytes, uint8_t *bins,
                          cabac_substream_result *results, uint32_t in_flight, uint32_t *select) {
   if (n_sub == 0) return hipSuccess;
   const int kind = variant & 0xff;
-  // auto: the quad decoder (four substreams per wave) has the shortest chain per bin at every batch size up to two quad waves
-  // per SIMD (C2: 10, C3: 256, C4: 4 096 substreams); from 9 216 about equally long substreams in flight sixteen per wave
+  // auto: up to 1 024 substreams in flight one substream per wave (C2: 10, C3: 256); then the quad decoder (four substreams per
+  // wave), the shortest chain per bin up to two quad waves per SIMD (C4: 4 096); from 9 216 about equally long substreams in flight sixteen per wave
   // decode 12 288 substreams in 2.23 ms against 3.14, 16 384 in 2.24 against 4.05
   if (kind == 0) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 0, select);
   if (kind == 4) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 16);
   if (kind == 8) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 4);
+  if (kind == 1) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 64);
   return hipErrorInvalidValue;
 }
 

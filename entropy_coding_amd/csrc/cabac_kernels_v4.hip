@@ -45,7 +45,12 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
 // permutation (quad_perm:[I,I,I,I])
 template <int L, int I>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
-  if constexpr (L == 16) return row_bcast<I>(v);
+  if constexpr (L == 64) {  // one substream per wave: a scalar — handed back in a vector register, so that the chain stays the
+    uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, I);  // vector code of the other geometries (as scalar code it is longer)
+    asm volatile("" : "+v"(r));
+    return r;
+  }
+  else if constexpr (L == 16) return row_bcast<I>(v);
   else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true);
 }
 
@@ -1360,10 +1365,12 @@ __device__ __forceinline__ void quad_dec_check(QuadDec &w, bool second) {
 // with 16 lanes, 16 with 4 — four steps of L bins consume at most 3 L bytes) if it is wanted
 template <int L = 16>
 __device__ __forceinline__ void quad_dec_stage_load(QuadDec &w, uint32_t j) {
-  w.pf_mask = neg_mask(w.filled - w.rp - 128u);  // fewer than 128 bytes ahead (filled >= rp always)
-  w.pf_off = w.filled + 4u * j;
+  constexpr uint32_t kLanes = L > 16 ? 16u : (uint32_t)L;  // a block is at most 64 bytes (the ring holds 256)
+  const uint32_t wanted = neg_mask(w.filled - w.rp - 128u);  // fewer than 128 bytes ahead (filled >= rp always)
+  w.pf_mask = L > 16 ? wanted & neg_mask(j - kLanes) : wanted;  // (with 64 lanes per substream the first 16 fetch)
+  w.pf_off = w.filled + 4u * (j & (kLanes - 1u));
   w.pf_data = *reinterpret_cast<const uint32_t *>(w.src_safe + min(w.pf_off, w.last_dword));
-  w.filled += (4u * L) & w.pf_mask;
+  w.filled += (4u * kLanes) & wanted;
 }
 // part 2 (the step after): into the ring; past the end of the substream the window is fed zeros
 __device__ __forceinline__ void quad_dec_stage_store(QuadDec &w) {
@@ -1388,13 +1395,34 @@ constexpr uint32_t kRingStride = 66;  // 64 ring dwords + the mirror of dword 0 
 // address by all lanes of a row IS the broadcast, and it replaces one v_mov_b32_dpp per bin and field (the consumers are
 // VOP3 / VOPC / SDWA encodings that cannot take a DPP operand themselves).
 template <int L = 16>
-struct QuadDecRow {
-  uint32_t c2[L], ctxm[L], srmul[L], ep[L], key[L];
+struct QuadDecRow {   // L = 64: the fields of sixteen bins at a time (quad_dec_steps fetches four times a step)
+  static constexpr int kN = L > 16 ? 16 : L;
+  uint32_t c2[kN], ctxm[kN], srmul[kN], ep[kN], key[kN];
+  // fields: this wave's parking area, [5][64] words — c2, ctxm, key, srmul, ep of the lanes' records; at: the first lane
+  __device__ __forceinline__ void fetch(const uint32_t *fields, uint32_t at) {
+    auto one = [&](uint32_t which, uint32_t (&dst)[kN]) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(fields + which * 64u + at);
+#pragma unroll
+      for (int q = 0; q < kN / 4; q++) {
+        const uint4 v = p[q];
+        dst[4 * q] = v.x;
+        dst[4 * q + 1] = v.y;
+        dst[4 * q + 2] = v.z;
+        dst[4 * q + 3] = v.w;
+      }
+    };
+    one(0, c2);
+    one(1, ctxm);
+    one(2, key);
+    one(3, srmul);
+    one(4, ep);
+  }
 };
 
 template <int I, bool kSpecial, int L = 16>
 __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDecRow<L> &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
-                                              uint32_t &bits, QuadDec &w) {
+                                              uint32_t (&bits)[2], QuadDec &w) {
+  constexpr int J = I % QuadDecRow<L>::kN;  // where bin I's fields sit in u
   // Input check only every 4th bin (4 bins consume at most 24 bits): 16-bit units are appended while fewer than
   // 32 look-ahead bits are valid.  The question is asked here, the answer acted upon at the END of this step: a
   // branch right behind the compare would stall ~55 cycles, and the step in between cannot be hurt — a decision
@@ -1407,25 +1435,34 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
     asm volatile("" : "+s"(refill), "+s"(refill2));
   }
   // the state of this bin's context, from the lane that holds the record; state() / getLPS, contexts.cpp:939-950
-  const uint32_t st = group_bcast<L, I>(st_v);
-  const uint32_t sum = (st & 0xffffu) + (st >> 16);  // the low half carries no rate bits here (see the kernel)
+  uint32_t sum;  // the two estimators added: the low half carries no rate bits here (see the kernel)
+  if constexpr (L == 64) {
+    // one substream per wave: the state crosses as a scalar and is consumed by the SDWA add at once; its result is a vector
+    // register, so that the chain stays the vector code of the other geometries (hipcc makes scalar code of a uniform chain,
+    // and that is longer: 157 instructions per four bins against 145)
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)st_v, I);
+    asm("v_add_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(sum) : "s"(st));
+  } else {
+    const uint32_t st = group_bcast<L, I>(st_v);
+    sum = (st & 0xffffu) + (st >> 16);
+  }
   const uint32_t sx = (uint32_t)((int32_t)(sum << 16) >> 31);  // 0 / ~0 from the MPS bit (bit 15)
   const uint32_t k = ((sum >> 10) ^ sx) & 31u;
-  const uint32_t t = (__umul24(w.range >> 5, k) + u.c2[I]) >> 1;
+  const uint32_t t = (__umul24(w.range >> 5, k) + u.c2[J]) >> 1;
   const uint32_t rm = w.range - t;
   // scaledRange at the window's scale is 2^22 (2^21 for a bypass bin) * rm.  (Round 1 had the scale as a DPP operand of a
   // multiplication, because v_lshlrev_b32 with DPP on its shift-amount operand returned wrong results on gfx950 — bisected
   // with the parity tests.)
   // value - scaledRange in ONE instruction: the record's field is MINUS the scale, a signed 24-bit factor (v_mad_i32_i24)
   uint32_t e;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e) : "v"(rm), "v"(u.srmul[I]), "v"(w.hi));
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e) : "v"(rm), "v"(u.srmul[J]), "v"(w.hi));
   // 0: value >= scaledRange (LPS / bin 1), ~0: MPS / bin 0.  Through asm so that hipcc sees an opaque mask: written
   // as (int)e >> 31 it turns every use back into v_cmp + v_cndmask pairs, two instructions where a v_bfi /
   // v_bitop3 on the mask is one.
   uint32_t ngem;
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(ngem) : "v"(e));
   const uint32_t bin = ~(ngem ^ sx) & 1u;                        // LPS ? !mps : mps; sx is the MPS as a mask (0 if st == 0)
-  const uint32_t gc = u.ctxm[I] & ~ngem;
+  const uint32_t gc = u.ctxm[J] & ~ngem;
   // One renormalisation rule for both paths: the chosen sub-range shifted up to [256, 511].  LPS (context bins only):
   // clz(t) - 23 is getRenormBitsLPS.  Otherwise rm >= 128 (an LPS width is at most 15.5 / 32 of the range plus 4), so
   // clz(rm) - 23 is 1 iff rm < 256 — the one-bit MPS renormalisation (arith_codec.cpp:60-73) — and 0 for a bypass bin
@@ -1448,13 +1485,14 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   {
     // (as DPP operands of their VOP2 consumers srmul and ep would cost no move, but hipcc then pads every such consumer
     // with s_nops — it applies the DPP read-after-write hazard to all of its operands: 122 s_nops per step against 38)
-    const uint32_t tot = nsh + u.ep[I];  // the renormalisation shift and the bypass bit
+    const uint32_t tot = nsh + u.ep[J];  // the renormalisation shift and the bypass bit
     const uint64_t v = (((uint64_t)w.hi << 32) | w.lo) << tot;
     w.hi = (uint32_t)(v >> 32);
     w.lo = (uint32_t)v;
     w.look -= (int32_t)tot;
   }
-  bits |= bin << I;
+  bits[I >> 5] |= bin << (I & 31);
+  if constexpr (L == 64) asm volatile("" : "+v"(bits[I >> 5]));  // now: left to itself hipcc keeps all 64 shifted bins and ORs them at the end
   // every lane applies the bin to its own copy of the state; the lanes of this row that hold the
   // same ctxId keep it (update(), contexts.cpp:903-913).
   // Both 15-bit estimators at once with packed 16-bit math: the halves never borrow or carry into each
@@ -1466,7 +1504,7 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
   uint32_t upd;  // both halves: rest + a * bin, the low half of `bin` feeding both lanes of the packed mad (op_sel_hi)
   asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(upd) : "v"(a_v), "v"(bin), "v"(rest));
   asm volatile("" : "+v"(upd));   // keep the update unconditional: hipcc would otherwise wrap it in an exec
-  st_v = (f.key == u.key[I]) ? upd : st_v;
+  st_v = (f.key == u.key[J]) ? upd : st_v;
   asm volatile("" : "+v"(st_v));  // region (SALU round trip + branch per bin)
   if ((I & 3) == 0 && refill != 0) {
     quad_dec_check(w, refill2 != 0);
@@ -1474,14 +1512,29 @@ __device__ __forceinline__ void quad_dec_step(const QuadDecInfo &f, const QuadDe
 }
 
 template <bool kSpecial, int L = 16>
-__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, const QuadDecRow<L> &u, uint32_t r0_v, uint32_t a_v, uint32_t &st_v,
-                                               uint32_t &bits, QuadDec &w) {
-#define QSTEP(I) quad_dec_step<I, kSpecial, L>(f, u, r0_v, a_v, st_v, bits, w)
-  QSTEP(0); QSTEP(1); QSTEP(2); QSTEP(3);
-  if constexpr (L == 16) {
-    QSTEP(4); QSTEP(5); QSTEP(6); QSTEP(7);
-    QSTEP(8); QSTEP(9); QSTEP(10); QSTEP(11); QSTEP(12); QSTEP(13); QSTEP(14); QSTEP(15);
+__device__ __forceinline__ void quad_dec_steps(const QuadDecInfo &f, QuadDecRow<L> &u, const uint32_t *fields, uint32_t r0_v, uint32_t a_v,
+                                               uint32_t &st_v, uint32_t (&bits)[2], QuadDec &w) {
+#define QSTEP(U, I) quad_dec_step<I, kSpecial, L>(f, U, r0_v, a_v, st_v, bits, w)
+#define QSTEP16(U, B)                                                                                                     \
+  QSTEP(U, B + 0); QSTEP(U, B + 1); QSTEP(U, B + 2); QSTEP(U, B + 3); QSTEP(U, B + 4); QSTEP(U, B + 5); QSTEP(U, B + 6);   \
+  QSTEP(U, B + 7); QSTEP(U, B + 8); QSTEP(U, B + 9); QSTEP(U, B + 10); QSTEP(U, B + 11); QSTEP(U, B + 12); QSTEP(U, B + 13); \
+  QSTEP(U, B + 14); QSTEP(U, B + 15)
+  if constexpr (L == 64) {
+    // sixty-four bins of ONE substream, the fields of sixteen at a time (a second set of eighty registers to fetch the next
+    // sixteen under the chain does not fit: 256 vector registers are addressable, the rest is reached through moves)
+    QSTEP16(u, 0);
+    u.fetch(fields, 16u);
+    QSTEP16(u, 16);
+    u.fetch(fields, 32u);
+    QSTEP16(u, 32);
+    u.fetch(fields, 48u);
+    QSTEP16(u, 48);
+  } else if constexpr (L == 16) {
+    QSTEP16(u, 0);
+  } else {
+    QSTEP(u, 0); QSTEP(u, 1); QSTEP(u, 2); QSTEP(u, 3);
   }
+#undef QSTEP16
 #undef QSTEP
 }
 
@@ -1566,11 +1619,12 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   w.look = 16;
   // the first 192 bytes go into the ring at once (blocks of 4 L bytes); the window itself started from bytes 0..3
   w.ring = ring_all + (wave * kSubs + row) * kRingStride;
-  for (uint32_t blk = 0; blk < 192u / (4u * L); blk++) {
-    w.filled = 4u * L * blk;
+  constexpr uint32_t kStageLanes = L > 16 ? 16u : (uint32_t)L;  // lanes that fetch a block (quad_dec_stage_load)
+  for (uint32_t blk = 0; blk < 192u / (4u * kStageLanes); blk++) {
+    w.filled = 4u * kStageLanes * blk;
     w.rp = 0;  // "wanted"
     quad_dec_stage_load<L>(w, j);
-    w.pf_mask = ~0u;
+    w.pf_mask = L > 16 ? neg_mask(j - kStageLanes) : ~0u;
     quad_dec_stage_store(w);
   }
   w.filled = 192;
@@ -1639,22 +1693,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    auto fetch = [&](uint32_t which, uint32_t (&dst)[L]) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(&field_all[wave][which][row * L]);
-#pragma unroll
-      for (int q = 0; q < L / 4; q++) {
-        const uint4 v = p[q];
-        dst[4 * q] = v.x;
-        dst[4 * q + 1] = v.y;
-        dst[4 * q + 2] = v.z;
-        dst[4 * q + 3] = v.w;
-      }
-    };
-    fetch(0, u.c2);
-    fetch(1, u.ctxm);
-    fetch(2, u.key);
-    fetch(3, u.srmul);
-    fetch(4, u.ep);
+    u.fetch(&field_all[wave][0][0], row * L);
   };
   request(0);
   prepare();
@@ -1664,13 +1703,14 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     // The bins of the previous step are stored only now, after the wait at the end of that step: loads and stores share
     // one in-order counter, so a store issued before a wait would add its whole latency to it (the same goes for the
     // input block requested a step ago: into the ring with it before anything new is issued)
-    if ((base & (3u * L)) == L) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
+    // (L = 64: a step consumes up to 48 bytes, so a 64-byte block is requested in EVERY step and stored in the next)
+    if (L == 64 ? base != 0u : (base & (3u * L)) == L) quad_dec_stage_store(w);     // steps 1, 5, 9, ...
     {  // under the lane mask asked for at the end of the step before: an `if` here is a compare the scalar unit waits for
       uint64_t saved;
       asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_byte %2, %3, off\n\ts_mov_b64 exec, %0"
                    : "=&s"(saved) : "s"(prev_lanes), "v"(out + min(prev_idx, last_rec)), "v"(prev_bin) : "memory");
     }
-    if ((base & (3u * L)) == 0u) quad_dec_stage_load<L>(w, j);    // steps 0, 4, 8, ...: request a block of input
+    if (L == 64 || (base & (3u * L)) == 0u) quad_dec_stage_load<L>(w, j);    // steps 0, 4, 8, ...: request a block of input
     const uint32_t id = cur_id, ctxm = cur_ctxm;
     // asked long ago, needed now (the choice of the step variant): the branch finds the answer waiting
     uint64_t special = cur_special;
@@ -1678,12 +1718,12 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
     uint32_t st_v = cur_stored & ctxm;
     const uint32_t a_v = cur_av, r0_v = cur_r0v;
     request(base + L);                                  // the ids and table rows of the next step
-    uint32_t bits = 0;  // row-uniform: bit I = the bin of record base + I
+    uint32_t bits[2] = {0u, 0u};  // row-uniform: bit I = the bin of record base + I
     V5_TICK(t2);
-    if (special == 0) quad_dec_steps<false, L>(f, u, r0_v, a_v, st_v, bits, w);
-    else quad_dec_steps<true, L>(f, u, r0_v, a_v, st_v, bits, w);
+    if (special == 0) quad_dec_steps<false, L>(f, u, &field_all[wave][0][0], r0_v, a_v, st_v, bits, w);
+    else quad_dec_steps<true, L>(f, u, &field_all[wave][0][0], r0_v, a_v, st_v, bits, w);
     V5_TICK(t3);
-    const uint32_t my_bin = (bits >> j) & 1u;
+    const uint32_t my_bin = ((L > 32 && j >= 32u ? bits[1] : bits[0]) >> (j & 31u)) & 1u;
     rctx[sel(ctxm, id, (uint32_t)kNumCtx)] = st_v;  // a lane without a context writes the pad word
     prev_bin = my_bin;
     prev_idx = base + j;
@@ -1714,7 +1754,7 @@ __global__ __launch_bounds__(64 * W) void decode_kernel_v4(uint32_t n_sub, const
   }
   if (bytes_read > w.cap) flags |= CABAC_RES_UNDERRUN;
   const uint64_t bad_mask = __ballot(bad != 0);
-  if ((bad_mask >> (row * L)) & ((1ull << L) - 1ull)) flags |= CABAC_RES_BAD_RECORD;
+  if ((bad_mask >> (row * L)) & (L == 64 ? ~0ull : (1ull << (L & 63)) - 1ull)) flags |= CABAC_RES_BAD_RECORD;
   if (live && j == 0) {
     cabac_substream_result res;
     res.n_bits = 8u * bytes_read + (uint32_t)bits_needed;
@@ -1889,12 +1929,15 @@ __global__ __launch_bounds__(1024) void decode_select_kernel(uint32_t n_sub, con
   }
 }
 
+constexpr uint32_t kSoloUpTo = 1024;  // substreams in flight up to which each gets a wave (and a SIMD) of its own
 constexpr uint32_t kHexFrom = 9216;  // measured (tools/batch_scaling.py): 8 192 equal substreams 2.12 ms quad / 2.23 ms hex, 12 288: 3.14 / 2.23
 
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                             const uint8_t *bytes, uint8_t *bins, cabac_substream_result *results, uint32_t in_flight, int lanes_per_sub,
                             uint32_t *select) {
   if (lanes_per_sub == 0) {  // auto
+    // up to one substream per SIMD: a wave each, 64 bins a step (16 ... 1 024 C4-type substreams 1.13-1.16 ms against 1.30)
+    if (max(n_sub, in_flight) <= kSoloUpTo) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 64);
     if (max(n_sub, in_flight) < kHexFrom || select == nullptr) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 16);
     // enough substreams for the sixteen-per-wave geometry IF they are about equally long: asked on the device, both
     // geometries launched, the one not chosen returns at once
@@ -1906,7 +1949,14 @@ hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
     return hipGetLastError();
   }
   const uint32_t waves = (n_sub + kQuadSubs - 1) / kQuadSubs;
-  if (lanes_per_sub == 4) {  // sixteen substreams per wave, 64 per workgroup (one workgroup's LDS fills most of a CU)
+  if (lanes_per_sub == 64) {  // one substream per wave, 64 bins per step: the per-step work around the chain is spread over 64 bins
+    if (max(n_sub, in_flight) >= 1024u)
+      hipLaunchKernelGGL((decode_kernel_v4<4, 64>), dim3((n_sub + 3u) / 4u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results,
+                         (const uint32_t *)nullptr, 0u);
+    else
+      hipLaunchKernelGGL((decode_kernel_v4<1, 64>), dim3(n_sub), dim3(64), 0, st, n_sub, desc, records, bytes, bins, results,
+                         (const uint32_t *)nullptr, 0u);
+  } else if (lanes_per_sub == 4) {  // sixteen substreams per wave, 64 per workgroup (one workgroup's LDS fills most of a CU)
     hipLaunchKernelGGL((decode_kernel_v4<4, 4>), dim3((n_sub + 63u) / 64u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results,
                        (const uint32_t *)nullptr, 0u);
   } else if ((max(n_sub, in_flight) + kQuadSubs - 1) / kQuadSubs >= 1024u) {

@@ -181,7 +181,9 @@ int cabac_hip_set_stream(cabac_hip_ctx *ctx, void *hip_stream);
 int cabac_hip_wait_event(cabac_hip_ctx *ctx, void *hip_event);
 int cabac_hip_record_event(cabac_hip_ctx *ctx, void *hip_event);
 int cabac_hip_synchronize(cabac_hip_ctx *ctx);
-/* kernel variant: 0 = default (fastest verified), others are listed in DESIGN.md */
+/* kernel variant: 0 = the dispatch (by batch size; the fastest verified).  Forcing one geometry — encode: 4, 6, 7; decode: 4 (four
+ * substreams per wave), 8 (sixteen per wave), 1 (one per wave) — is for measurements and the parity matrix;
+ * any other number makes the next launch fail                                                                            */
 int cabac_hip_set_variant(cabac_hip_ctx *ctx, int encode_variant, int decode_variant);
 
 /* ---- device-pointer entry points (asynchronous on the ctx stream) ---

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 # auto = the dispatch (encode v7 from 3 072 substreams, v6 below; decode v4); 4 / 6 / 7 force one encoder generation
 # (the generations v1-v3 and v5 were retired in round 3: cabac_hip_set_variant refuses them)
 # decode: 4 = the quad decoder (four substreams per wave), 8 = sixteen substreams per wave (dispatched for big batches)
-VARIANTS = {"auto": (0, 0), "v4": (4, 4), "v6": (6, 0), "v7": (7, 0), "dec16": (0, 8)}
+VARIANTS = {"auto": (0, 0), "v4": (4, 4), "v6": (6, 0), "v7": (7, 0), "dec16": (0, 8), "dec1": (0, 1)}
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))

@@ -1,6 +1,7 @@
 """Throughput against batch size: C4-type substreams (16 384 bins, 75 % context coded), 1 024 ... 16 384 of them in
 one launch.  python tools/batch_scaling.py [decode variants ...]  (on an MI355X; default: 0 = the dispatch, 4 = four
-substreams per wave, 8 = sixteen)"""
+substreams per wave, 8 = sixteen, 1 = one)
+python tools/batch_scaling.py small [variants ...]: 16 ... 2 048 substreams instead (the one-substream-per-wave geometry's range)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,8 +9,9 @@ from entropy_coding_amd import capi
 from entropy_coding_amd.workload import CONFIGS, build_batch
 
 hip = capi.CabacHip(0, stream=torch.cuda.current_stream().cuda_stream)
-dec_variants = [int(v) for v in sys.argv[1:]] or [0, 4, 8]
-for n_sub in (1024, 2048, 4096, 8192, 12288, 16384, 32768):
+small = len(sys.argv) > 1 and sys.argv[1] == "small"
+dec_variants = [int(v) for v in sys.argv[(2 if small else 1):]] or ([0, 4, 1] if small else [0, 4, 8])
+for n_sub in ((16, 64, 256, 512, 768, 1024, 1536, 2048) if small else (1024, 2048, 4096, 8192, 12288, 16384, 32768)):
     desc, records, bytes_total = build_batch(CONFIGS["C4"], first=0, count=n_sub)
     n_bins = int(desc["n_records"].astype(np.int64).sum())
     t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
