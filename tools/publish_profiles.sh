@@ -4,7 +4,7 @@
 TAG=${1:-r03a}
 R=${TAG%[a-z]}
 F=gpurun_out/final_$TAG
-for f in batch_scaling e2e_chunks pcie_probe enc_scaling; do
+for f in batch_scaling batch_scaling_small e2e_chunks pcie_probe enc_scaling; do
   [ -f $F/$f.txt ] && grep -v amdgpu.ids $F/$f.txt > profiles/${R}_$f.txt
 done
 for w in C2 C3 C4 C5 C5_strong_1gpu C4_2rank_rehearsal C3_strong_2rank_rehearsal; do [ -f $F/bench_$w.json ] && grep '^{' $F/bench_$w.json > profiles/${R}_final_bench_$w.json; done   # (gloo prints its connection lines to stdout)
