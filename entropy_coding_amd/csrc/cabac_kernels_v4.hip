@@ -1929,7 +1929,40 @@ __global__ __launch_bounds__(1024) void decode_select_kernel(uint32_t n_sub, con
   }
 }
 
-constexpr uint32_t kSoloUpTo = 1024;  // substreams in flight up to which each gets a wave (and a SIMD) of its own
+// Between 1 024 and 3 072 substreams: is the batch's time that of at most 1 024 long substreams that come first (a share of a
+// longest-first sharded batch: BASELINE config C5 on four GPUs is 1 024 long + 1 024 short ones)?  Then one substream per wave
+// (*select = 2: the long ones get a SIMD each, the short ones pass through beside them), else four (0).  "Long": more than a
+// sixteenth of the longest.  They must come first because workgroups are placed in order: two long waves on one SIMD would
+// cost more than the geometry saves.
+__global__ __launch_bounds__(1024) void decode_select_solo_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
+                                                                  uint32_t max_long, uint32_t *__restrict__ select) {
+  __shared__ uint32_t red[16];
+  __shared__ uint32_t longest;
+  auto block_max = [&](uint32_t v) {
+    for (int d = 1; d < 64; d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int k = 0; k < 16; k++) m = max(m, red[k]);
+    return m;
+  };
+  uint32_t mx = 0;
+  for (uint32_t s = threadIdx.x; s < n_sub; s += 1024u) mx = max(mx, desc[s].n_records);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) longest = mx;
+  __syncthreads();
+  const uint32_t cut = longest >> 4;
+  uint32_t past = 0;  // 1 + the index of the last long substream
+  for (uint32_t s = threadIdx.x; s < n_sub; s += 1024u)
+    if (desc[s].n_records > cut) past = s + 1u;
+  past = block_max(past);
+  // all long ones among the first max_long: then there are at most max_long of them
+  if (threadIdx.x == 0) *select = (longest != 0u && past <= max_long) ? 2u : 0u;
+}
+
+constexpr uint32_t kSoloUpTo = 1024;
+constexpr uint32_t kSoloAskUpTo = 3072;  // ... and up to here the batch is looked at on the device (below the headline's 4 096)  // substreams in flight up to which each gets a wave (and a SIMD) of its own
 constexpr uint32_t kHexFrom = 9216;  // measured (tools/batch_scaling.py): 8 192 equal substreams 2.12 ms quad / 2.23 ms hex, 12 288: 3.14 / 2.23
 
 hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
@@ -1938,6 +1971,12 @@ hipError_t launch_decode_v4(hipStream_t st, uint32_t n_sub, const cabac_substrea
   if (lanes_per_sub == 0) {  // auto
     // up to one substream per SIMD: a wave each, 64 bins a step (16 ... 1 024 C4-type substreams 1.13-1.16 ms against 1.30)
     if (max(n_sub, in_flight) <= kSoloUpTo) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 64);
+    if (select != nullptr && max(n_sub, in_flight) <= kSoloAskUpTo && in_flight <= n_sub) {  // (not for chunks of a bigger batch)
+      hipLaunchKernelGGL(decode_select_solo_kernel, dim3(1), dim3(1024), 0, st, n_sub, desc, kSoloUpTo, select);
+      hipLaunchKernelGGL((decode_kernel_v4<4, 64>), dim3((n_sub + 3u) / 4u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results, select, 2u);
+      hipLaunchKernelGGL((decode_kernel_v4<4, 16>), dim3((n_sub + 15u) / 16u), dim3(256), 0, st, n_sub, desc, records, bytes, bins, results, select, 0u);
+      return hipGetLastError();
+    }
     if (max(n_sub, in_flight) < kHexFrom || select == nullptr) return launch_decode_v4(st, n_sub, desc, records, bytes, bins, results, in_flight, 16);
     // enough substreams for the sixteen-per-wave geometry IF they are about equally long: asked on the device, both
     // geometries launched, the one not chosen returns at once

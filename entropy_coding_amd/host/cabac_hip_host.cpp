@@ -262,7 +262,9 @@ void HipBatch::deliverBytes(Pending &p, const uint8_t *src, uint32_t nbits) {
 }
 
 namespace {
-// longest-processing-time-first: item k (weight w[k]) to the least loaded of n_bins bins; items keep their order in a bin
+// longest-processing-time-first: item k (weight w[k]) to the least loaded of n_bins bins; a bin holds its items longest first
+// (a wave decodes consecutive substreams and runs as long as its longest; and a share whose few long substreams come first gets
+// a wave per substream from the decode dispatch)
 std::vector<std::vector<uint32_t>> lptAssign(const std::vector<uint64_t> &w, size_t n_bins) {
   std::vector<uint32_t> order(w.size());
   for (uint32_t k = 0; k < order.size(); k++) order[k] = k;
@@ -274,7 +276,6 @@ std::vector<std::vector<uint32_t>> lptAssign(const std::vector<uint64_t> &w, siz
     bins[b].push_back(k);
     load[b] += w[k] + 1;
   }
-  for (auto &b : bins) std::sort(b.begin(), b.end());
   return bins;
 }
 

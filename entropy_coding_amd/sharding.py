@@ -26,7 +26,9 @@ from . import capi
 
 def lpt_assign(n_records, world):
     """Longest-processing-time-first bin packing of substreams onto `world` ranks by bin count.
-    Returns a list (per rank) of substream indices, each in ascending order."""
+    Returns a list (per rank) of substream indices, each LONGEST FIRST (equal lengths in their original order): a wave holds
+    consecutive substreams of a shard and runs as long as its longest, and the decode dispatch gives a shard whose few long
+    substreams come first a wave per substream (csrc/cabac_kernels_v4.hip, decode_select_solo_kernel)."""
     order = np.argsort(-np.asarray(n_records, np.int64), kind="stable")
     load = np.zeros(world, np.int64)
     owner = [[] for _ in range(world)]
@@ -34,7 +36,7 @@ def lpt_assign(n_records, world):
         r = int(np.argmin(load))
         owner[r].append(int(s))
         load[r] += int(n_records[s])
-    return [sorted(o) for o in owner]
+    return owner
 
 
 def _dev():

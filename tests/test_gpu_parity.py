@@ -355,11 +355,47 @@ def test_decode_dispatch_on_big_batches(mix):
     hip.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["long_first", "long_last", "all_long"])
+def test_decode_dispatch_on_ragged_mid_size_batches(order):
+    """Between 1 024 and 3 072 substreams the dispatch asks the device whether the batch is a few long substreams in front of
+    many short ones (a share of a longest-first sharded batch: decode_select_solo_kernel) and launches the one-substream-per-wave
+    and the quad geometry, one of which returns at once.  Whichever runs, the bins, bit counts and flags are the oracle's."""
+    orc = H.load_oracle()
+    rng = np.random.default_rng({"long_first": 11, "long_last": 12, "all_long": 13}[order])
+    n_sub = 2048
+    lens = rng.integers(40, 90, size=n_sub)
+    if order == "all_long":
+        lens[:] = rng.integers(1500, 2500, size=n_sub)
+    else:
+        where = slice(0, 900) if order == "long_first" else slice(n_sub - 900, n_sub)
+        lens[where] = rng.integers(2500, 4000, size=900)
+    recs = [H.random_records(rng, int(n) - 1, end_trm=True) for n in lens]
+    lens = [len(r) for r in recs]
+    records = np.concatenate(recs)
+    desc, total = H.make_desc(lens, rng.integers(0, 64, size=n_sub), rng.integers(0, 3, size=n_sub), H.SUB_FINISH | H.SUB_ALIGN_RBSP)
+    out_o, res_o = orc.encode_batch(desc, records, total)
+    dd = desc.copy()
+    dd["byte_capacity"] = (res_o["n_bits"] + 7) // 8
+    bins_o, ro = orc.decode_batch(dd, records, out_o)
+    import torch
+    hip = H.gpu_ctx()
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt).reshape(-1).copy()).cuda()
+    t_desc, t_rec, t_bytes = dev(dd, np.uint8), dev(records, np.int16), dev(out_o, np.uint8)
+    t_bins = torch.full((len(records),), 7, dtype=torch.uint8, device="cuda")
+    t_res = torch.zeros(2 * n_sub, dtype=torch.int32, device="cuda")
+    hip.decode_device(n_sub, t_desc.data_ptr(), t_rec.data_ptr(), t_bytes.data_ptr(), t_bins.data_ptr(), t_res.data_ptr())
+    rd = t_res.cpu().numpy().view(H.RESULT_DTYPE)
+    assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"]) and not rd["flags"].any()
+    assert np.array_equal(t_bins.cpu().numpy(), bins_o)
+    hip.close()
+
+
 def test_retired_variants_are_refused():
     """Variant numbers of the retired generations fail loudly at launch instead of falling back to another kernel."""
     desc, total = H.make_desc([4], [30], [2], H.SUB_FINISH)
     rec = H.random_records(np.random.default_rng(1), 3)
-    for v in (1, 2, 3, 5, 9):
+    for v in (1, 2, 3, 5, 9):              # (encode numbers; decode 1 is the one-substream-per-wave geometry)
         c = H.gpu_ctx()
         c.set_variant(v, 0)
         with pytest.raises(capi.CabacHipError):

@@ -71,6 +71,8 @@ def test_lpt_assign_balances_mixed_lengths():
     loads = [int(n[o].sum()) for o in owners]
     assert sorted(sum(owners, [])) == list(range(len(n)))
     assert max(loads) - min(loads) <= 2048 * 8
+    for o in owners:                                   # every shard longest first
+        assert all(n[a] >= n[b] for a, b in zip(o, o[1:]))
 
 
 def _orc_residual(tus, coeff):

@@ -10,9 +10,10 @@ from entropy_coding_amd.workload import CONFIGS, build_batch
 
 hip = capi.CabacHip(0, stream=torch.cuda.current_stream().cuda_stream)
 small = len(sys.argv) > 1 and sys.argv[1] == "small"
-dec_variants = [int(v) for v in sys.argv[(2 if small else 1):]] or ([0, 4, 1] if small else [0, 4, 8])
-for n_sub in ((16, 64, 256, 512, 768, 1024, 1536, 2048) if small else (1024, 2048, 4096, 8192, 12288, 16384, 32768)):
-    desc, records, bytes_total = build_batch(CONFIGS["C4"], first=0, count=n_sub)
+share = len(sys.argv) > 1 and sys.argv[1] == "share"   # the shares of C5 sharded longest-first over 2, 4, 8 GPUs (long + short halves)
+dec_variants = [int(v) for v in sys.argv[(2 if small or share else 1):]] or ([0, 4, 1] if small or share else [0, 4, 8])
+for n_sub in ((4096, 2048, 1024) if share else (16, 64, 256, 512, 768, 1024, 1536, 2048) if small else (1024, 2048, 4096, 8192, 12288, 16384, 32768)):
+    desc, records, bytes_total = build_batch(CONFIGS["C5" if share else "C4"], first=0, count=n_sub)
     n_bins = int(desc["n_records"].astype(np.int64).sum())
     t_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
     t_rec = torch.from_numpy(records.view(np.int16)).cuda()
