@@ -94,7 +94,7 @@ def run(a):
         rng = np.random.default_rng(seed)
         desc, records, total = draw_batch(rng)
         enc = int(rng.choice([0, 4, 6, 7]))
-        hip.set_variant(enc, int(rng.choice([0, 4, 8])))
+        hip.set_variant(enc, int(rng.choice([0, 4, 8, 1])))
         out_o, res_o = orc.encode_batch(desc, records, total)
         out_g, res_g = hip.encode_batch(desc, records, total, check=False)
         what = "round %d (seed %d, %d substreams, encoder %d)" % (rounds, seed, len(desc), enc)
