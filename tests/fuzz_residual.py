@@ -36,7 +36,17 @@ def binariser_round(hip, rng, n_blocks):
             blocks.append(H.random_block(rng, w, h, density=float(rng.choice([0.02, 0.05, 0.3, 0.7, 1.0])), big=float(rng.choice([0.0, 0.05, 0.3])),
                                          huge=0.02 if rng.random() < 0.1 else 0.0, last_frac=float(rng.choice([1.0, 0.5, 0.2, 0.05]))))
             fl = int(rng.integers(0, 8))
-            flags.append(fl & ~H.TU_TS_FLAG if max(w, h) > 32 else fl)
+            fl = fl & ~H.TU_TS_FLAG if max(w, h) > 32 else fl
+            if max(w, h) <= 32 and rng.random() < 0.2:       # SBT / MTS zero-out: what lies outside the left / upper 16 is zero
+                fl |= H.TU_SBT_ZERO_OUT
+                c = blocks[-1]
+                if w == 32:
+                    c[:, 16:] = 0
+                if h == 32:
+                    c[16:, :] = 0
+                if not c.any():
+                    c[0, 0] = 3
+            flags.append(fl)
         chromas.append(int(rng.integers(0, 2)))
     B.check_against_oracle(hip, blocks, chromas, flags, slack=int(rng.integers(0, 2)))
     return sum(b.size for b in blocks)
