@@ -602,8 +602,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # CABAC_BENCH_DIST_ONE=1 (rehearsal, 1-GPU box): a process group of ONE rank, so that every collective and the scatter / gather of
+    # the multi-GPU path run through RCCL on device tensors (tests/test_gpu_rccl_one_rank.py)
+    multi = world > 1 or os.environ.get("CABAC_BENCH_DIST_ONE") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -623,7 +629,7 @@ def main():
             worder = build_batch.last_order
             whole = (wdesc, torch.from_numpy(wrec.view(np.int16)).cuda())       # the batch resident on the ingest GPU
             del wrec
-        if world > 1:
+        if multi:
             barrier_sync = lambda: (torch.cuda.synchronize(), dist.barrier())
             barrier_sync()
             t0 = time.perf_counter()
@@ -661,7 +667,7 @@ def main():
                           t_res_d.data_ptr())
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -677,7 +683,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -706,7 +712,7 @@ def main():
         t_offs = torch.zeros(n_sub + 1, dtype=torch.int64, device="cuda")
         hip.assemble_device(n_sub, t_desc.data_ptr(), t_res_e.data_ptr(), t_bytes.data_ptr(), t_pay.data_ptr(), out_bytes, t_offs.data_ptr())
         hip.synchronize()
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
@@ -730,7 +736,7 @@ def main():
             del streams
         # ... and every substream of every rank's shard against the checker's bytes (the golden md5s cover a sample)
         whole_hash = whole_batch_hash(desc, t_rec.cpu().numpy().view(np.uint16), res_e, t_bytes.cpu().numpy())
-        if world > 1:
+        if multi:
             t = torch.tensor([whole_hash["substreams"], whole_hash["differ"]], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(t)
             whole_hash.update(substreams=int(t[0].item()), differ=int(t[1].item()), match=int(t[1].item()) == 0)
@@ -748,7 +754,7 @@ def main():
                     hash_match = hash_match and hashlib.md5(host_bytes[o:o + nb].tobytes()).hexdigest() == g["md5"]
         # ... and every substream of every rank's batch against the checker's bytes (the golden md5s above cover a sample)
         whole_hash = whole_batch_hash(desc, records, res_e, host_bytes)
-        if world > 1:
+        if multi:
             t = torch.tensor([whole_hash["substreams"], whole_hash["differ"]], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(t)
             whole_hash.update(substreams=int(t[0].item()), differ=int(t[1].item()), match=int(t[1].item()) == 0)
@@ -804,7 +810,7 @@ def main():
 
     # ---- untimed gather of the per-substream sizes over RCCL (the only exchange the path has) ---
     gather_ms = None
-    if world > 1:
+    if multi:
         if not args.strong:
             sizes = t_res_e.view(-1, 2)[:, 0].contiguous().to(coll_dev)
             allsz = [torch.empty_like(sizes) for _ in range(world)]
@@ -818,7 +824,7 @@ def main():
         ok = bool(flag.item())
 
     bins_all = n_bins * world
-    if args.strong and world > 1:
+    if args.strong and multi:
         t = torch.tensor([n_bins], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t)
         bins_all = int(t.item())
@@ -923,7 +929,7 @@ def main():
         # a failure of the untimed legs is reported inside their own objects (`residual`, `assemble`), not here
         print(json.dumps(line))
     hip.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if rank == 0 and not (hash_match and ok):
         sys.exit(1)
