@@ -32,6 +32,23 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DESC_BYTES, RESULT_BYTES = 32, 8
 
 
+def decode_geometry(dec_variant, n_records):
+    """Substreams per wave the decode dispatch picks for this batch (mirror of launch_decode_v4 in csrc/cabac_kernels_v4.hip)."""
+    forced = {4: 4, 8: 16, 1: 1}.get(dec_variant & 0xFF)
+    if forced:
+        return forced
+    n = np.asarray(n_records, np.int64)
+    n_sub, longest = len(n), int(n.max()) if len(n) else 0
+    if n_sub <= 1024:
+        return 1
+    if n_sub <= 3072:   # decode_select_solo_kernel: the substreams longer than a sixteenth of the longest all among the first 1 024?
+        where = np.nonzero(n > (longest >> 4))[0]
+        return 1 if longest and len(where) and int(where[-1]) < 1024 else 4
+    if n_sub >= 9216 and longest and int(n.sum()) >= 9216 * longest:
+        return 16
+    return 4
+
+
 def kernel_names(enc_variant, dec_variant, n_sub):
     """Which kernels the library dispatches to (mirror of launch_encode/launch_decode in csrc/cabac_kernels.hip)."""
     enc = {4: "v4", 6: "v6", 7: "v7"}.get(enc_variant & 0xFF, "v7" if n_sub >= 3072 else "v6")
@@ -868,6 +885,8 @@ def main():
             # each), the sixteen-per-wave decoder is dispatched from 9 216 about equally long substreams; `equal_substreams` is
             # the batch's bins over its longest substream's — the number that decides how busy the chip can be kept
             "occupancy": {"substreams": n_sub, "equal_substreams": round(n_bins / max(int(desc["n_records"].max()), 1), 1),
+                          "decode_substreams_per_wave": decode_geometry(args.dec_variant, desc["n_records"]),
+                          "decode_waves_per_simd": round(-(-n_sub // decode_geometry(args.dec_variant, desc["n_records"])) / 1024.0, 3),
                           "quad_decode_waves_per_simd": round(((n_sub + 3) // 4) / 1024.0, 3),
                           "long_chain_waves_per_simd": round(((n_bins // max(int(desc["n_records"].max()), 1) + 3) // 4) / 1024.0, 3)},
             "encode_mbins_s": round(n_bins / (enc_avg * 1e-3) / 1e6, 2),
@@ -910,6 +929,9 @@ def main():
                               "scatter_ms": None if scatter_ms is None else round(scatter_ms, 3),
                               "gather_ms": None if gather_ms_strong is None else round(gather_ms_strong, 3),
                               "scatter_bytes": 2 * bins_all, "gathered_payload_bytes": total_payload,
+                              "waves_per_simd": {"this_rank": round(-(-n_sub // decode_geometry(args.dec_variant, desc["n_records"])) / 1024.0, 3),
+                                                 "long_chains": round(n_bins / max(int(desc["n_records"].max()), 1) / decode_geometry(args.dec_variant, desc["n_records"]) / 1024.0, 3),
+                                                 "decode_substreams_per_wave": decode_geometry(args.dec_variant, desc["n_records"])},
                               "what": "scatter / gather are outside the timed region: the step is encode + decode of the resident shard"}
         if world == 1 and not args.no_co_scheduled and not args.strong:
             try:
