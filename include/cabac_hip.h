@@ -190,7 +190,11 @@ int cabac_hip_set_variant(cabac_hip_ctx *ctx, int encode_variant, int decode_var
  * Replace: BinEncoderBase::reset/start + TBinEncoder::encodeBin + encodeBinEP +
  * encodeBinTrm + writeOut + finish (arith_codec.cpp:329-357, :367-370, :389-399,
  * :460-478, :524-582) and Ctx::init (contexts.cpp:996-1015, :1133-1145) for a
- * batch of n_sub substreams.  All pointers are device memory.                */
+ * batch of n_sub substreams.  All pointers are device memory.
+ * Order: any.  Consecutive descriptors share a wave (decode: one, four or sixteen substreams per wave by batch size; encode: four
+ * or sixteen) and a wave runs as long as its longest substream, so a batch of very unequal substreams is coded fastest with
+ * its descriptors longest first — which is also what lets the decode dispatch give a few long substreams in front of many
+ * short ones a wave each (the shards of sharding.py and of the C++ HipBatch are ordered that way).                        */
 int cabac_hip_encode_device(cabac_hip_ctx *ctx, uint32_t n_sub,
                             const cabac_substream_desc *d_desc, const uint16_t *d_records,
                             uint8_t *d_bytes, cabac_substream_result *d_results);
