@@ -514,6 +514,23 @@ def residual_leg(hip, n_tiles, unique=256, reps=4, host_e2e=True):
                                        "mbins_s": round(n_bins / min(t_h[1:]) / 1e6, 1), "h2d_bytes": int(4 * c_u * copies + 24 * n + 38 * n_tiles),
                                        "d2h_bytes": int(out_bytes + 16 * n_tiles), "bytes_match": e2e_ok}
         spliced_ok = spliced_ok and e2e_ok
+        # ... and with the coefficients as int16 (cabac_hip_encode_batch_residual16; what the C++ shim's staging area hands over when
+        # the blocks' dynamic range is 15 bits): 2 bytes per coefficient go up
+        if int(coeff.min()) >= -32768 and int(coeff.max()) <= 32767:
+            keep.append(capi.PinnedArray((c_u * copies,), np.int16))
+            for r in range(copies):
+                keep[2].array[r * c_u:(r + 1) * c_u] = coeff
+            t_h = []
+            for _ in range(3):
+                keep[1].array[:] = 0
+                t0 = time.perf_counter()
+                h_off, h_res = hip.encode_batch_residual(sp_desc, sp_rec, sp_first, sp_list, all_tus, keep[2].array, keep[1].array)
+                t_h.append(time.perf_counter() - t0)
+            ok16 = bool(np.array_equal(h_res["n_bits"], res["n_bits"])) and bool(np.array_equal(keep[1].array[:out_bytes], host_pay[:out_bytes]))
+            spliced["from_pinned_host_int16"] = {"call_ms": round(min(t_h[1:]) * 1e3, 3), "mcoeff_s": round(c_u * copies / min(t_h[1:]) / 1e6, 1),
+                                                 "mbins_s": round(n_bins / min(t_h[1:]) / 1e6, 1),
+                                                 "h2d_bytes": int(2 * c_u * copies + 24 * n + 38 * n_tiles), "bytes_match": ok16}
+            spliced_ok = spliced_ok and ok16
         for kp in keep:
             kp.close()
     ok = ok and spliced_ok

@@ -40,7 +40,8 @@ EXPORTS = [
     "cabac_hip_estimate_device", "cabac_hip_estimate_batch", "cabac_hip_estimate_from_device",
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
     "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload", "cabac_hip_wait_event", "cabac_hip_record_event",
-    "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual", "cabac_hip_gather_records_device",
+    "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual", "cabac_hip_encode_residual16_device",
+    "cabac_hip_encode_batch_residual16", "cabac_hip_gather_records_device",
 ]
 
 _lib = None
@@ -105,7 +106,11 @@ def load_library():
     L.cabac_hip_encode_batch_payload.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_encode_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp,
                                                    vp, ctypes.c_uint64, vp, vp, vp, vp]
+    L.cabac_hip_encode_residual16_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp,
+                                                   vp, ctypes.c_uint64, vp, vp, vp, vp]
     L.cabac_hip_encode_batch_residual.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint32, vp, vp,
+                                                  ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, vp]
+    L.cabac_hip_encode_batch_residual16.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint32, vp, vp,
                                                   ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, vp]
     L.cabac_hip_gather_records_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.cabac_hip_last_kernel_ms.restype = ctypes.c_float
@@ -367,28 +372,31 @@ class CabacHip:
         return records[: int(offsets[n])], offsets, info[:n]
 
     def encode_residual_device(self, n_sub, d_desc, d_records, d_splice_first, d_splices, n_splice, n_tu, d_tu, d_coeff,
-                               d_payload, payload_capacity, d_payload_offsets, d_results, d_tu_info=0, d_bin_counts=0):
-        """cabac_hip_encode_residual_device: host records + spliced coefficient blocks -> compacted coded substreams."""
-        self._check(self.L.cabac_hip_encode_residual_device(
+                               d_payload, payload_capacity, d_payload_offsets, d_results, d_tu_info=0, d_bin_counts=0, int16=False):
+        """cabac_hip_encode_residual_device (int16: cabac_hip_encode_residual16_device, d_coeff holds int16 coefficients): host
+        records + spliced coefficient blocks -> compacted coded substreams."""
+        self._check((self.L.cabac_hip_encode_residual16_device if int16 else self.L.cabac_hip_encode_residual_device)(
             self.h, n_sub, vp(d_desc), vp(d_records), vp(d_splice_first), vp(d_splices) if d_splices else None, n_splice, n_tu,
             vp(d_tu) if d_tu else None, vp(d_coeff) if d_coeff else None, vp(d_payload), payload_capacity, vp(d_payload_offsets),
             vp(d_results), vp(d_tu_info) if d_tu_info else None, vp(d_bin_counts) if d_bin_counts else None))
 
     def encode_batch_residual(self, desc, records, splice_first, splices, tus, coeff, payload, check=True, with_info=False,
                               with_counts=False):
-        """cabac_hip_encode_batch_residual (host arrays, synchronous): (offsets uint64[n + 1], results[, tu_info][, counts])."""
+        """cabac_hip_encode_batch_residual (host arrays, synchronous): (offsets uint64[n + 1], results[, tu_info][, counts]).
+        int16 coefficients go through cabac_hip_encode_batch_residual16."""
+        narrow = isinstance(coeff, np.ndarray) and coeff.dtype == np.int16
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         records = np.ascontiguousarray(records, np.uint16)
         splice_first = np.ascontiguousarray(splice_first, np.uint32)
         splices = np.ascontiguousarray(splices, SPLICE_DTYPE)
         tus = np.ascontiguousarray(tus, TU_DTYPE)
-        coeff = np.ascontiguousarray(coeff, np.int32)
+        coeff = np.ascontiguousarray(coeff, np.int16 if narrow else np.int32)
         n = len(desc)
         offsets = np.zeros(n + 1, np.uint64)
         res = np.zeros(max(n, 1), RESULT_DTYPE)
         info = np.zeros(max(len(tus), 1), np.uint32) if with_info else None
         counts = np.zeros((max(n, 1), BIN_COUNT_WORDS), np.uint32) if with_counts else None
-        rc = self.L.cabac_hip_encode_batch_residual(
+        rc = (self.L.cabac_hip_encode_batch_residual16 if narrow else self.L.cabac_hip_encode_batch_residual)(
             self.h, n, desc.ctypes.data, records.ctypes.data, len(records), splice_first.ctypes.data, splices.ctypes.data,
             len(tus), tus.ctypes.data, coeff.ctypes.data, len(coeff), payload.ctypes.data, payload.nbytes, offsets.ctypes.data,
             res.ctypes.data, info.ctypes.data if with_info else None, counts.ctypes.data if with_counts else None)

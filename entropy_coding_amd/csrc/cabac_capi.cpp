@@ -880,7 +880,7 @@ int cabac_hip_residual_device(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_de
   if (int rc = ensure(c, 5, cabac::residual_scratch_bytes(n_tu))) return rc;
   Bracket br = bracket_for(c, 5);
   HIP_TRY(c, hipEventRecord(br.a, c->stream));
-  HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, d_rec_offset, d_n_records, d_info, d_records,
+  HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, 4, d_rec_offset, d_n_records, d_info, d_records,
                                     c->d_buf[5]));
   HIP_TRY(c, hipEventRecord(br.b, c->stream));
   c->timed = (br.a == c->ev_start);
@@ -1022,11 +1022,11 @@ struct Timed {  // profile-ring bracket around a group of launches (nothing when
 };
 }  // namespace
 
-int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint16_t *d_records,
-                                     const uint32_t *d_splice_first, const cabac_splice *d_splices, uint32_t n_splice, uint32_t n_tu,
-                                     const cabac_tu_desc *d_tu, const int32_t *d_coeff, uint8_t *d_payload, uint64_t payload_capacity,
-                                     uint64_t *d_payload_offsets, cabac_substream_result *d_results, uint32_t *d_tu_info,
-                                     uint32_t *d_bin_counts) {
+static int encode_residual_device_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                                       const uint32_t *d_splice_first, const cabac_splice *d_splices, uint32_t n_splice, uint32_t n_tu,
+                                       const cabac_tu_desc *d_tu, const void *d_coeff, int coeff_bytes, uint8_t *d_payload,
+                                       uint64_t payload_capacity, uint64_t *d_payload_offsets, cabac_substream_result *d_results,
+                                       uint32_t *d_tu_info, uint32_t *d_bin_counts) {
   if (!c || !d_payload_offsets || (n_sub && (!d_desc || !d_records || !d_splice_first || !d_payload || !d_results)) ||
       (n_splice && !d_splices) || (n_tu && (!d_tu || !d_coeff)))
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
@@ -1052,7 +1052,7 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cab
   c->timed = false;
   {  // block sizes (pass 1 of the binariser)
     Timed t(c, 5);
-    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, nullptr, d_cnt, d_info, nullptr, c->d_buf[5]));
+    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, coeff_bytes, nullptr, d_cnt, d_info, nullptr, c->d_buf[5]));
   }
   {
     Timed t(c, 10);
@@ -1074,7 +1074,7 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cab
   }
   {  // block records (pass 2), straight into the expanded substreams
     Timed t(c, 5);
-    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, tu_off, d_cnt, d_info, exp_rec, c->d_buf[5],
+    HIP_TRY(c, cabac::launch_residual(c->stream, n_tu, d_tu, d_coeff, coeff_bytes, tu_off, d_cnt, d_info, exp_rec, c->d_buf[5],
                                       /*order_ready=*/true));  // the block order of the sizes pass above: same tus[], same scratch
   }
   {
@@ -1093,9 +1093,27 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cab
   return CABAC_HIP_OK;
 }
 
+int cabac_hip_encode_residual_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                                     const uint32_t *d_splice_first, const cabac_splice *d_splices, uint32_t n_splice, uint32_t n_tu,
+                                     const cabac_tu_desc *d_tu, const int32_t *d_coeff, uint8_t *d_payload, uint64_t payload_capacity,
+                                     uint64_t *d_payload_offsets, cabac_substream_result *d_results, uint32_t *d_tu_info,
+                                     uint32_t *d_bin_counts) {
+  return encode_residual_device_impl(c, n_sub, d_desc, d_records, d_splice_first, d_splices, n_splice, n_tu, d_tu, d_coeff, 4, d_payload,
+                                     payload_capacity, d_payload_offsets, d_results, d_tu_info, d_bin_counts);
+}
+
+int cabac_hip_encode_residual16_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint16_t *d_records,
+                                       const uint32_t *d_splice_first, const cabac_splice *d_splices, uint32_t n_splice, uint32_t n_tu,
+                                       const cabac_tu_desc *d_tu, const int16_t *d_coeff, uint8_t *d_payload, uint64_t payload_capacity,
+                                       uint64_t *d_payload_offsets, cabac_substream_result *d_results, uint32_t *d_tu_info,
+                                       uint32_t *d_bin_counts) {
+  return encode_residual_device_impl(c, n_sub, d_desc, d_records, d_splice_first, d_splices, n_splice, n_tu, d_tu, d_coeff, 2, d_payload,
+                                     payload_capacity, d_payload_offsets, d_results, d_tu_info, d_bin_counts);
+}
+
 static int encode_batch_residual_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                                       uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
-                                      const cabac_tu_desc *tus, const int32_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                      const cabac_tu_desc *tus, const void *coeff, int coeff_bytes, uint64_t n_coeff_total, uint8_t *payload,
                                       uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
                                       uint32_t *tu_info, uint32_t *bin_counts) {
   if (!c || !payload_offsets || (n_sub && (!desc || !splice_first || !results || !payload)) || (n_tu && (!tus || !coeff || !splices)))
@@ -1119,7 +1137,7 @@ static int encode_batch_residual_impl(cabac_hip_ctx *c, uint32_t n_sub, const ca
   if ((rc = ensure(c, kSpInFirst, first_bytes))) return rc;
   if ((rc = ensure(c, kSpInSplice, size_t(n_splice ? n_splice : 1) * sizeof(cabac_splice)))) return rc;
   if ((rc = ensure(c, kSpInTu, size_t(n_tu ? n_tu : 1) * sizeof(cabac_tu_desc)))) return rc;
-  if ((rc = ensure(c, kSpInCoeff, (n_coeff_total + 4) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, kSpInCoeff, (n_coeff_total + 4) * size_t(coeff_bytes)))) return rc;
   if ((rc = ensure(c, kSpOutRes, n_sub * sizeof(cabac_substream_result)))) return rc;
   if ((rc = ensure(c, kSpOutInfo, size_t(n_tu ? n_tu : 1) * sizeof(uint32_t)))) return rc;
   if (bin_counts && (rc = ensure(c, kSpOutCnt, size_t(n_sub) * CABAC_BIN_COUNT_WORDS * sizeof(uint32_t)))) return rc;
@@ -1146,15 +1164,15 @@ static int encode_batch_residual_impl(cabac_hip_ctx *c, uint32_t n_sub, const ca
   if ((rc = h2d(c, c->d_buf[kSpInFirst], splice_first, first_bytes, c->s_in))) return rc;
   if ((rc = h2d(c, c->d_buf[kSpInSplice], splices, size_t(n_splice) * sizeof(cabac_splice), c->s_in))) return rc;
   if ((rc = h2d(c, c->d_buf[kSpInRec], records, n_records_total * sizeof(uint16_t), c->s_in))) return rc;
-  if ((rc = h2d(c, c->d_buf[kSpInCoeff], coeff, n_coeff_total * sizeof(int32_t), c->s_in))) return rc;
+  if ((rc = h2d(c, c->d_buf[kSpInCoeff], coeff, n_coeff_total * size_t(coeff_bytes), c->s_in))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev_in[1], c->s_in));
   HIP_TRY(c, hipEventSynchronize(c->ev_k[0]));
   if (*h_flag) return fail(c, CABAC_HIP_ERR_INVALID, "coefficients out of range");
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in[1], 0));
-  rc = cabac_hip_encode_residual_device(c, n_sub, static_cast<const cabac_substream_desc *>(c->d_buf[kSpInDesc]),
+  rc = encode_residual_device_impl(c, n_sub, static_cast<const cabac_substream_desc *>(c->d_buf[kSpInDesc]),
                                         static_cast<const uint16_t *>(c->d_buf[kSpInRec]), static_cast<const uint32_t *>(c->d_buf[kSpInFirst]),
                                         static_cast<const cabac_splice *>(c->d_buf[kSpInSplice]), n_splice, n_tu,
-                                        static_cast<const cabac_tu_desc *>(c->d_buf[kSpInTu]), static_cast<const int32_t *>(c->d_buf[kSpInCoeff]),
+                                        static_cast<const cabac_tu_desc *>(c->d_buf[kSpInTu]), c->d_buf[kSpInCoeff], coeff_bytes,
                                         static_cast<uint8_t *>(c->d_buf[6]), payload_capacity, static_cast<uint64_t *>(c->d_buf[7]),
                                         static_cast<cabac_substream_result *>(c->d_buf[kSpOutRes]), static_cast<uint32_t *>(c->d_buf[kSpOutInfo]),
                                         bin_counts ? static_cast<uint32_t *>(c->d_buf[kSpOutCnt]) : nullptr);
@@ -1188,7 +1206,17 @@ int cabac_hip_encode_batch_residual(cabac_hip_ctx *c, uint32_t n_sub, const caba
                                     const cabac_tu_desc *tus, const int32_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
                                     uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
                                     uint32_t *tu_info, uint32_t *bin_counts) {
-  return host_call_exit(c, encode_batch_residual_impl(c, n_sub, desc, records, n_records_total, splice_first, splices, n_tu, tus, coeff,
+  return host_call_exit(c, encode_batch_residual_impl(c, n_sub, desc, records, n_records_total, splice_first, splices, n_tu, tus, coeff, 4,
+                                                      n_coeff_total, payload, payload_capacity, payload_offsets, results, tu_info,
+                                                      bin_counts));
+}
+
+int cabac_hip_encode_batch_residual16(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                      uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
+                                      const cabac_tu_desc *tus, const int16_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                      uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
+                                      uint32_t *tu_info, uint32_t *bin_counts) {
+  return host_call_exit(c, encode_batch_residual_impl(c, n_sub, desc, records, n_records_total, splice_first, splices, n_tu, tus, coeff, 2,
                                                       n_coeff_total, payload, payload_capacity, payload_offsets, results, tu_info,
                                                       bin_counts));
 }

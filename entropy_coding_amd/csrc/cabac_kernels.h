@@ -45,7 +45,8 @@ hipError_t launch_binarize(hipStream_t st, uint32_t n_sub, const uint64_t *se_of
 // scratch: residual_scratch_bytes(n_tu) bytes of device memory the launch may overwrite (block ordering)
 size_t residual_scratch_bytes(uint32_t n_tu);
 // order_ready: `scratch` still holds the block order of an earlier launch over the SAME tus[] (the sizes pass of this call)
-hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+// coeff_bytes: 4 (int32_t, the reference's TCoeff) or 2 (int16_t: blocks of 15-bit dynamic range)
+hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const void *coeff, int coeff_bytes,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
                            void *scratch, bool order_ready = false);
 

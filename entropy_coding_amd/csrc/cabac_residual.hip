@@ -262,9 +262,11 @@ __global__ __launch_bounds__(256) void class_scatter(uint32_t n_tu, const cabac_
 // kSingle: every block of the workgroup is ONE coefficient group (class 0: 4 x 4 and smaller, 2 x 8, 1 x 16): no group
 // scan, no group flags, the coefficient is loaded once, and the template of a position never leaves the block — it is read
 // from the row's own lanes (five ds_bpermute of a packed contribution word) instead of five loads.
-template <bool kWrite, uint32_t kStageDw, bool kTs, bool kSingle = false>
+// C: how the coefficients lie in memory — int32_t (the reference's TCoeff) or int16_t (what a block whose dynamic range is 15 bits
+// needs: half the bytes over PCIe for the host-pointer path, cabac_hip_encode_batch_residual16)
+template <bool kWrite, uint32_t kStageDw, bool kTs, bool kSingle = false, class C = int32_t>
 __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage, uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
-                                              const int32_t *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
+                                              const C *__restrict__ coeff_all, const uint64_t *__restrict__ rec_offset,
                                               uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
                                               uint16_t *__restrict__ records, const uint32_t *__restrict__ perm) {
   const uint32_t lane = threadIdx.x & 63u, l = lane & 15u, row_shift = lane & 48u;
@@ -273,7 +275,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
   // ---- geometry (row-uniform) -------------------------------------------------------------------
   uint32_t lw = 0, lh = 0, chroma = 0, flags = 0, max_log2 = 15;
-  const int32_t *coeff = coeff_all;
+  const C *coeff = coeff_all;
   if (live) {
     const cabac_tu_desc d = tus[tu_idx];
     lw = d.log2_width;
@@ -753,9 +755,9 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 // class 4 (256 coded coefficients: 1 KB per row), then the rest, read directly.  The staged launches are small grids
 // whose workgroups take their range in turn; the direct launch has one workgroup per 16 rows, and those that fall into
 // a staged range leave at once.
-template <bool kWrite, uint32_t kStageDw>
+template <bool kWrite, uint32_t kStageDw, class C>
 __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const cabac_tu_desc *__restrict__ tus,
-                                                        const int32_t *__restrict__ coeff_all,
+                                                        const C *__restrict__ coeff_all,
                                                         const uint64_t *__restrict__ rec_offset,
                                                         uint32_t *__restrict__ n_records,
                                                         uint32_t *__restrict__ info_out,
@@ -768,25 +770,25 @@ __global__ __launch_bounds__(256) void residual_kernel(uint32_t n_tu, const caba
   const uint32_t mid_wgs = ((class_count[4] + r) & ~r) / kRowsPerBlock;
   if (kStageDw == 1024u) {
     for (uint32_t wg = blockIdx.x; wg < big_wgs; wg += gridDim.x)
-      residual_rows<kWrite, 1024u, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, 1024u, false, false, C>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   } else if (kStageDw == 256u) {
     for (uint32_t wg = big_wgs + blockIdx.x; wg < big_wgs + mid_wgs; wg += gridDim.x)
-      residual_rows<kWrite, 256u, false>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, 256u, false, false, C>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   } else if (blockIdx.x >= big_wgs + mid_wgs) {
     // class 0 — one group per block — comes last in the order and takes the lean walk
     const uint32_t single_from = big_wgs + mid_wgs + (((class_count[3] + r) & ~r) + ((class_count[2] + r) & ~r) + ((class_count[1] + r) & ~r)) / kRowsPerBlock;
     if (blockIdx.x >= single_from)
-      residual_rows<kWrite, 0u, false, true>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, 0u, false, true, C>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
     else
-      residual_rows<kWrite, 0u, false>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+      residual_rows<kWrite, 0u, false, false, C>(blockIdx.x, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
   }
 }
 
 // Transform-skip blocks: a small grid that leaves at once when the batch holds none (the ordering pre-pass notes it),
 // and otherwise goes over all row groups, taking the flagged blocks.
-template <bool kWrite>
+template <bool kWrite, class C>
 __global__ __launch_bounds__(256) void residual_ts_kernel(uint32_t n_tu, uint32_t n_wg, const cabac_tu_desc *__restrict__ tus,
-                                                           const int32_t *__restrict__ coeff_all,
+                                                           const C *__restrict__ coeff_all,
                                                            const uint64_t *__restrict__ rec_offset,
                                                            uint32_t *__restrict__ n_records, uint32_t *__restrict__ info_out,
                                                            uint16_t *__restrict__ records, const uint32_t *__restrict__ perm,
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void residual_ts_kernel(uint32_t n_tu, uint32_
   __shared__ int32_t stage[1];
   if (header[kScratchAnyTs] == 0u) return;
   for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x)
-    residual_rows<kWrite, 0u, true>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
+    residual_rows<kWrite, 0u, true, false, C>(wg, stage, n_tu, tus, coeff_all, rec_offset, n_records, info_out, records, perm);
 }
 
 // (the residual parser lives in cabac_residual_parse.hip)
@@ -803,8 +805,8 @@ size_t residual_scratch_bytes(uint32_t n_tu) {
   return sizeof(uint32_t) * (kScratchHeader + (size_t)n_tu + kClasses * kRowsPerBlock);
 }
 
-template <bool kWrite>
-static hipError_t launch_residual_passes(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+template <bool kWrite, class C>
+static hipError_t launch_residual_passes(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const C *coeff,
                                          const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
                                          uint32_t *s32, uint32_t rows) {
   // (The three launches side by side on three streams, the staged ones holding few waves per CU, were measured: 1.53 ms
@@ -812,21 +814,22 @@ static hipError_t launch_residual_passes(hipStream_t st, uint32_t n_tu, const ca
   const dim3 grid(rows / kRowsPerBlock);
   const dim3 grid_staged(grid.x < 1024u ? grid.x : 1024u), grid_mid(grid.x < 8192u ? grid.x : 8192u);
   const uint32_t *order = s32 + kScratchHeader;
-  hipLaunchKernelGGL((residual_kernel<kWrite, 1024u>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+  hipLaunchKernelGGL((residual_kernel<kWrite, 1024u, C>), grid_staged, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                      records, order, s32);
-  hipLaunchKernelGGL((residual_kernel<kWrite, 256u>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+  hipLaunchKernelGGL((residual_kernel<kWrite, 256u, C>), grid_mid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                      records, order, s32);
-  hipLaunchKernelGGL((residual_kernel<kWrite, 0u>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
+  hipLaunchKernelGGL((residual_kernel<kWrite, 0u, C>), grid, dim3(256), 0, st, n_tu, tus, coeff, rec_offset, n_records, info,
                      records, order, s32);
-  hipLaunchKernelGGL((residual_ts_kernel<kWrite>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
+  hipLaunchKernelGGL((residual_ts_kernel<kWrite, C>), grid_staged, dim3(256), 0, st, n_tu, grid.x, tus, coeff, rec_offset, n_records,
                      info, records, order, s32);
   return hipGetLastError();
 }
 
-hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const int32_t *coeff,
+hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *tus, const void *coeff, int coeff_bytes,
                            const uint64_t *rec_offset, uint32_t *n_records, uint32_t *info, uint16_t *records,
                            void *scratch, bool order_ready) {
   if (n_tu == 0) return hipSuccess;
+  if (coeff_bytes != 4 && coeff_bytes != 2) return hipErrorInvalidValue;
   // blocks ordered by group count: [counts | cursors | permutation, 0xFFFFFFFF where a class is padded to 16 rows]
   uint32_t *s32 = static_cast<uint32_t *>(scratch);
   const uint32_t rows = n_tu + kClasses * kRowsPerBlock;  // upper bound of the padded list
@@ -839,8 +842,14 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
     hipLaunchKernelGGL(class_hist, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
     hipLaunchKernelGGL(class_scatter, dim3(g), dim3(256), 0, st, n_tu, tus, s32);
   }
-  return records ? launch_residual_passes<true>(st, n_tu, tus, coeff, rec_offset, n_records, info, records, s32, rows)
-                 : launch_residual_passes<false>(st, n_tu, tus, coeff, rec_offset, n_records, info, records, s32, rows);
+  if (coeff_bytes == 2) {
+    const int16_t *c16 = static_cast<const int16_t *>(coeff);
+    return records ? launch_residual_passes<true, int16_t>(st, n_tu, tus, c16, rec_offset, n_records, info, records, s32, rows)
+                   : launch_residual_passes<false, int16_t>(st, n_tu, tus, c16, rec_offset, n_records, info, records, s32, rows);
+  }
+  const int32_t *c32 = static_cast<const int32_t *>(coeff);
+  return records ? launch_residual_passes<true, int32_t>(st, n_tu, tus, c32, rec_offset, n_records, info, records, s32, rows)
+                 : launch_residual_passes<false, int32_t>(st, n_tu, tus, c32, rec_offset, n_records, info, records, s32, rows);
 }
 
 }  // namespace cabac

@@ -240,11 +240,48 @@ cabac_tu_desc makeTuDesc(const HipBatch::ResidualBlock &b, uint64_t coeff_offset
   return t;
 }
 
-uint64_t HipBatch::stageCoefficients(const int32_t *coeff, size_t n) {
-  const uint64_t at = m_stageCoeff.size();
+uint64_t HipBatch::stageCoefficients(const int32_t *coeff, size_t n, int maxLog2TrDynamicRange) {
+  const uint64_t at = stagedCoefficients();
+  if (m_narrow && (maxLog2TrDynamicRange == 0 || maxLog2TrDynamicRange <= 15)) {
+    m_stageCoeff16.resize(at + n);
+    int16_t *dst = m_stageCoeff16.data() + at;
+    uint32_t outside = 0;
+    for (size_t i = 0; i < n; i++) {
+      dst[i] = int16_t(coeff[i]);
+      outside |= (uint32_t(coeff[i]) + 32768u) >> 16;  // non-zero iff the value does not fit
+    }
+    if (!outside) {
+      m_stagedBlocksOpen++;
+      return at;
+    }
+    m_stageCoeff16.resize(at);  // a coefficient beyond the range the block declares: keep it as it is, in 32 bits
+  }
+  if (m_narrow) {  // from here on the staging area is the reference's TCoeff
+    m_stageCoeff.assign(m_stageCoeff16.begin(), m_stageCoeff16.end());
+    m_stageCoeff16.clear();
+    m_narrow = false;
+  }
   m_stageCoeff.insert(m_stageCoeff.end(), coeff, coeff + n);
   m_stagedBlocksOpen++;
   return at;
+}
+
+void HipBatch::clearStage() {
+  m_stageCoeff.clear();
+  m_stageCoeff16.clear();
+  m_narrow = true;
+}
+
+uint64_t HipBatch::restage(HipBatch &from, uint64_t at, size_t n) {
+  if (!from.m_narrow) return stageCoefficients(from.m_stageCoeff.data() + at, n, 16);  // (wide stays wide)
+  const uint64_t to = stagedCoefficients();
+  if (m_narrow) {
+    m_stageCoeff16.insert(m_stageCoeff16.end(), from.m_stageCoeff16.begin() + at, from.m_stageCoeff16.begin() + at + n);
+  } else {
+    m_stageCoeff.insert(m_stageCoeff.end(), from.m_stageCoeff16.begin() + at, from.m_stageCoeff16.begin() + at + n);
+  }
+  m_stagedBlocksOpen++;
+  return to;
 }
 
 // the coded substream into its container, leaving it as the reference's finish() leaves its bitstream
@@ -324,7 +361,7 @@ void HipBatch::flush() {
         HipBatch &peer = *m_peers[dv - 1];
         for (cabac_tu_desc &t : p.blocks) {
           const size_t n = size_t(1) << (t.log2_width + t.log2_height);
-          t.coeff_offset = peer.stageCoefficients(m_stageCoeff.data() + t.coeff_offset, n);
+          t.coeff_offset = peer.restage(*this, t.coeff_offset, n);
         }
         moved_blocks += p.blocks.size();
       }
@@ -336,7 +373,7 @@ void HipBatch::flush() {
     if (dv == 0) flushLocal(part[0]);
     else m_peers[dv - 1]->flushLocal(part[dv]);
   });
-  if (m_stagedBlocksOpen == 0) m_stageCoeff.clear();
+  if (m_stagedBlocksOpen == 0) clearStage();
 }
 
 void HipBatch::flushLocal(std::vector<Pending> &done) {
@@ -403,19 +440,23 @@ void HipBatch::flushSpliced(std::vector<Pending> &done) {
   std::vector<uint64_t> offsets(size_t(n) + 1, 0);
   std::vector<uint32_t> info(tus.size() ? tus.size() : 1, 0), counts(want_counts ? size_t(n) * CABAC_BIN_COUNT_WORDS : 0);
   // The coded size is only known on the device.  A first guess from the input sizes; the call says when it does not fit.
-  size_t capacity = std::max<size_t>(size_t(1) << 16, rec_total + m_stageCoeff.size() / 2);
+  size_t capacity = std::max<size_t>(size_t(1) << 16, rec_total + stagedCoefficients() / 2);
   int rc = CABAC_HIP_OK;
   for (int attempt = 0; attempt < 6; attempt++) {
     if (m_stageBytes.size() < capacity) m_stageBytes.resize(capacity);
-    rc = cabac_hip_encode_batch_residual(handle(), n, desc.data(), records.data(), rec_total, first.data(), splices.data(),
-                                         uint32_t(tus.size()), tus.data(), m_stageCoeff.data(), m_stageCoeff.size(), m_stageBytes.data(),
-                                         m_stageBytes.size(), offsets.data(), res.data(), info.data(),
-                                         want_counts ? counts.data() : nullptr);
+    rc = m_narrow ? cabac_hip_encode_batch_residual16(handle(), n, desc.data(), records.data(), rec_total, first.data(), splices.data(),
+                                                      uint32_t(tus.size()), tus.data(), m_stageCoeff16.data(), m_stageCoeff16.size(),
+                                                      m_stageBytes.data(), m_stageBytes.size(), offsets.data(), res.data(), info.data(),
+                                                      want_counts ? counts.data() : nullptr)
+                  : cabac_hip_encode_batch_residual(handle(), n, desc.data(), records.data(), rec_total, first.data(), splices.data(),
+                                                    uint32_t(tus.size()), tus.data(), m_stageCoeff.data(), m_stageCoeff.size(),
+                                                    m_stageBytes.data(), m_stageBytes.size(), offsets.data(), res.data(), info.data(),
+                                                    want_counts ? counts.data() : nullptr);
     if (rc != CABAC_HIP_ERR_INVALID || std::string(cabac_hip_last_error(m_ctx)) != "payload_capacity too small") break;
     capacity *= 4;
   }
   m_stagedBlocksOpen -= std::min<size_t>(m_stagedBlocksOpen, size_t(n_blocks));
-  if (m_stagedBlocksOpen == 0) m_stageCoeff.clear();  // (blocks of encoders still recording keep their place otherwise)
+  if (m_stagedBlocksOpen == 0) clearStage();  // (blocks of encoders still recording keep their place otherwise)
   if (rc == CABAC_HIP_ERR_SUBSTREAM)
     for (uint32_t t = 0; t < tus.size(); t++)
       if (info[t] & CABAC_TU_INFO_EMPTY) throw Exception("Coefficient coding called for empty TU");
@@ -645,7 +686,7 @@ void BinEncoderHip::encodeResidual(const HipBatch::ResidualBlock &b) {
   if (!b.coeff) fail("encodeResidual: block without coefficients");
   if (b.tsFlag) fail("encodeResidual: code transform_skip_flag with encodeBin before the block (tsFlag must be false)");
   cabac_tu_desc t = makeTuDesc(b, 0);
-  t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height);
+  t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height, b.maxLog2TrDynamicRange);
   m_splices.push_back(cabac_splice{uint32_t(m_records.size()), uint32_t(m_blocks.size())});
   m_blocks.push_back(t);
 }

@@ -239,8 +239,11 @@ public:
 
   // Coefficients of blocks whose bins are spliced into a substream on the device (BinEncoderHip::encodeResidual): one
   // staging area per batch (page-locked under usePinnedMirrors), so that a flush hands the C ABI one contiguous region.
-  // Returns the offset (in coefficients) of the copy.
-  uint64_t stageCoefficients(const int32_t *coeff, size_t n);
+  // Returns the offset (in coefficients) of the copy.  The copy is narrowed to int16 on the way — half the bytes over PCIe
+  // (cabac_hip_encode_batch_residual16) — as long as every staged block has a 15-bit dynamic range (maxLog2TrDynamicRange
+  // 15, the value of all of the reference's cfgs) and its coefficients keep to it; the first block that does not turns the
+  // staging area back into the reference's 32-bit TCoeff.
+  uint64_t stageCoefficients(const int32_t *coeff, size_t n, int maxLog2TrDynamicRange = 15);
 
   // One finished, not yet coded substream.  Either `sink` (this namespace's OutputBitstream) or
   // `deliver` (any other container, e.g. the reference's Common::OutputBitstream through
@@ -279,8 +282,13 @@ private:
   // that with pinned mirrors the page-locking is paid once
   RecordVector m_stageRecords;
   ByteVector m_stageBytes;
-  std::vector<int32_t, HostAllocator<int32_t>> m_stageCoeff;
+  std::vector<int32_t, HostAllocator<int32_t>> m_stageCoeff;    // used when !m_narrow
+  std::vector<int16_t, HostAllocator<int16_t>> m_stageCoeff16;  // used while m_narrow
+  bool m_narrow = true;
   size_t m_stagedBlocksOpen = 0;  // blocks staged by encoders that have not been flushed yet
+  size_t stagedCoefficients() const { return m_narrow ? m_stageCoeff16.size() : m_stageCoeff.size(); }
+  void clearStage();
+  uint64_t restage(HipBatch &from, uint64_t at, size_t n);  // a block of `from`'s staging area into this one (multi-device flush)
   std::vector<std::unique_ptr<HipBatch>> m_peers;  // the other devices of a multi-device batch (each a plain one-device batch)
 #ifdef CABAC_HOST_TEST_OTHER_LAYOUT  // tests/test_host_shim.py: a caller compiled from "another version" of this header
   void *m_memberOfAnotherVersion = nullptr;

@@ -348,6 +348,14 @@ int cabac_hip_encode_residual_device(cabac_hip_ctx *ctx, uint32_t n_sub, const c
                                      uint32_t n_splice, uint32_t n_tu, const cabac_tu_desc *d_tu, const int32_t *d_coeff,
                                      uint8_t *d_payload, uint64_t payload_capacity, uint64_t *d_payload_offsets,
                                      cabac_substream_result *d_results, uint32_t *d_tu_info, uint32_t *d_bin_counts);
+/* The same with the coefficients as int16_t (tus[].coeff_offset counts int16_t then): for blocks whose dynamic range is 15 bits
+ * (max_log2_tr_range 15, every coefficient in [-32768, 32767] — all of the reference's cfgs), half the bytes to move.  What a
+ * caller that copies its TCoeff blocks into a staging buffer anyway (the C++ shim does) narrows on the way.               */
+int cabac_hip_encode_residual16_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                       const uint16_t *d_records, const uint32_t *d_splice_first, const cabac_splice *d_splices,
+                                       uint32_t n_splice, uint32_t n_tu, const cabac_tu_desc *d_tu, const int16_t *d_coeff,
+                                       uint8_t *d_payload, uint64_t payload_capacity, uint64_t *d_payload_offsets,
+                                       cabac_substream_result *d_results, uint32_t *d_tu_info, uint32_t *d_bin_counts);
 
 /* Host-pointer form (synchronous): pinned caller memory is DMA'd where it lies, pageable memory goes through the bounce ring.
  * payload / payload_offsets / results / tu_info / bin_counts as above, in host memory.  Returns CABAC_HIP_ERR_SUBSTREAM if a
@@ -358,6 +366,13 @@ int cabac_hip_encode_batch_residual(cabac_hip_ctx *ctx, uint32_t n_sub, const ca
                                     uint64_t n_coeff_total, uint8_t *payload, uint64_t payload_capacity,
                                     uint64_t *payload_offsets, cabac_substream_result *results, uint32_t *tu_info,
                                     uint32_t *bin_counts);
+/* ... with int16_t coefficients (see cabac_hip_encode_residual16_device): 2 instead of 4 bytes per coefficient over PCIe      */
+int cabac_hip_encode_batch_residual16(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                                      const uint16_t *records, uint64_t n_records_total, const uint32_t *splice_first,
+                                      const cabac_splice *splices, uint32_t n_tu, const cabac_tu_desc *tus, const int16_t *coeff,
+                                      uint64_t n_coeff_total, uint8_t *payload, uint64_t payload_capacity,
+                                      uint64_t *payload_offsets, cabac_substream_result *results, uint32_t *tu_info,
+                                      uint32_t *bin_counts);
 
 /* ---- substream assembly on the device --------------
  * assemble: concatenate the coded substreams in descriptor order into d_payload — the effect of

@@ -99,7 +99,7 @@ public:
     } catch (const EntropyCodingAMD::Exception &e) {
       HIPREF_THROW(e.what());
     }
-    t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height);
+    t.coeff_offset = m_batch.stageCoefficients(b.coeff, size_t(b.width) * b.height, b.maxLog2TrDynamicRange);
     m_splices.push_back(cabac_splice{uint32_t(m_records.size()), uint32_t(m_blocks.size())});
     m_blocks.push_back(t);
     m_blockInfo.push_back(std::move(onInfo));

@@ -303,6 +303,17 @@ int cabac_hip_encode_batch_residual(cabac_hip_ctx *c, uint32_t n_sub, const caba
   return status;
 }
 
+int cabac_hip_encode_batch_residual16(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                      uint64_t n_records_total, const uint32_t *splice_first, const cabac_splice *splices, uint32_t n_tu,
+                                      const cabac_tu_desc *tus, const int16_t *coeff, uint64_t n_coeff_total, uint8_t *payload,
+                                      uint64_t payload_capacity, uint64_t *payload_offsets, cabac_substream_result *results,
+                                      uint32_t *tu_info, uint32_t *bin_counts) {
+  if (n_tu && !coeff) return fail(c, CABAC_HIP_ERR_INVALID, "null");
+  std::vector<int32_t> wide(coeff, coeff + (coeff ? n_coeff_total : 0));
+  return cabac_hip_encode_batch_residual(c, n_sub, desc, records, n_records_total, splice_first, splices, n_tu, tus, wide.data(), n_coeff_total,
+                                         payload, payload_capacity, payload_offsets, results, tu_info, bin_counts);
+}
+
 int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
                                    uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
                                    uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {

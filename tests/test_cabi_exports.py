@@ -13,7 +13,7 @@ from entropy_coding_amd import capi
 def _declared_symbols():
     hdr = open(os.path.join(H.ROOT, "include", "cabac_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(cabac_(?:hip|synth)_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(cabac_(?:hip|synth)_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_every_declared_symbol_is_exported():

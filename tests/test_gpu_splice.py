@@ -83,22 +83,25 @@ def counts_of(rec):
 
 
 @pytest.mark.parametrize("seed,n_sub,max_blocks", [(1, 40, 12), (2, 300, 40), (3, 5, 700), (4, 3100, 6)])
-@pytest.mark.parametrize("pinned", [False, True])
-def test_spliced_residual_matches_oracle(seed, n_sub, max_blocks, pinned):
+@pytest.mark.parametrize("pinned,narrow", [(False, False), (True, False), (False, True), (True, True)])
+def test_spliced_residual_matches_oracle(seed, n_sub, max_blocks, pinned, narrow):
+    """narrow: the coefficients as int16 (cabac_hip_encode_batch_residual16) — the same blocks, the same bytes."""
     hip = capi.CabacHip(0)
+    cdt = np.int16 if narrow else np.int32
     rng = np.random.default_rng(0x5111CE + seed)
     desc, records, first, splices, tus, coeff, expanded = build_case(rng, n_sub, max_blocks)
     want, want_bits = expected(desc, expanded)
     total = sum(len(b) for b in want)
     keep = []
     if pinned:
-        keep = [capi.PinnedArray((max(len(coeff), 1),), np.int32), capi.PinnedArray((max(len(records), 1),), np.uint16),
+        keep = [capi.PinnedArray((max(len(coeff), 1),), cdt), capi.PinnedArray((max(len(records), 1),), np.uint16),
                 capi.PinnedArray((total + 64,), np.uint8)]
         keep[0].array[:len(coeff)] = coeff
         keep[1].array[:len(records)] = records
         coeff_in, rec_in, payload = keep[0].array[:len(coeff)], keep[1].array[:len(records)], keep[2].array
     else:
-        coeff_in, rec_in, payload = coeff, records, np.zeros(total + 64, np.uint8)
+        coeff_in, rec_in, payload = coeff.astype(cdt), records, np.zeros(total + 64, np.uint8)
+    assert np.array_equal(coeff_in.astype(np.int32), coeff)
     for rep in range(2):                                   # the same ctx again: staging is reused
         payload[:] = 0xEE
         offs, res, info, counts = hip.encode_batch_residual(desc, rec_in, first, splices, tus, coeff_in, payload, with_info=True,
@@ -131,16 +134,18 @@ def test_spliced_residual_device_pointers_through_every_encoder():
     dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt).reshape(-1).copy()).cuda()
     t_desc, t_rec, t_first = dev(desc, np.uint8), dev(records, np.int16), dev(first, np.int32)
     t_sp, t_tu, t_co = dev(splices, np.uint8), dev(tus, np.uint8), dev(coeff, np.int32)
-    for variant in (0, 4, 6, 7):
+    t_co16 = dev(coeff.astype(np.int16), np.int16)
+    for variant in (0, 4, 6, 7, 16):                       # (16: the dispatched encoder on int16 coefficients)
         hip = H.gpu_ctx()
+        narrow, variant = variant == 16, variant % 16
         hip.set_variant(variant, 0)
         t_pay = torch.full((total + 64,), 0xEE, dtype=torch.uint8, device="cuda")
         t_off = torch.zeros(len(desc) + 1, dtype=torch.int64, device="cuda")
         t_res = torch.zeros(2 * len(desc), dtype=torch.int32, device="cuda")
         t_cnt = torch.zeros(len(desc) * capi.BIN_COUNT_WORDS, dtype=torch.int32, device="cuda")
         hip.encode_residual_device(len(desc), t_desc.data_ptr(), t_rec.data_ptr(), t_first.data_ptr(), t_sp.data_ptr(), len(splices),
-                                   len(tus), t_tu.data_ptr(), t_co.data_ptr(), t_pay.data_ptr(), total + 64, t_off.data_ptr(),
-                                   t_res.data_ptr(), 0, t_cnt.data_ptr())
+                                   len(tus), t_tu.data_ptr(), (t_co16 if narrow else t_co).data_ptr(), t_pay.data_ptr(), total + 64,
+                                   t_off.data_ptr(), t_res.data_ptr(), 0, t_cnt.data_ptr(), int16=narrow)
         hip.synchronize()
         res = t_res.cpu().numpy().view(H.RESULT_DTYPE)
         offs = t_off.cpu().numpy()

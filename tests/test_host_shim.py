@@ -373,11 +373,13 @@ def test_shim_get_num_written_bits_immediate_mode(drv):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_shim_spliced_residual_blocks(drv, mode):
+@pytest.mark.parametrize("mode,wide", [(0, False), (1, False), (2, False), (0, True), (2, True)])
+def test_shim_spliced_residual_blocks(drv, mode, wide):
     """BinEncoderHip::encodeResidual: coefficients handed over where the reference's writer would call residual_coding
     (cabac_writer.cpp:2424-2525), their bins spliced in between the recorded ones on the device at flush().  Bytes and
-    BinCounter totals against the oracle coding the same substreams from host-side records."""
+    BinCounter totals against the oracle coding the same substreams from host-side records.
+    The batch's staging area narrows the coefficients to int16 on the way in; wide: a block in the middle of the batch holds a
+    coefficient that does not fit, which turns the staging area — the blocks already in it included — back into 32 bits."""
     orc = H.load_oracle()
     rng = np.random.default_rng(170 + mode)
     n = 9
@@ -392,6 +394,8 @@ def test_shim_spliced_residual_blocks(drv, mode):
             ts = w <= 32 and rng.random() < 0.3
             fl = (int(rng.integers(0, 2)) | H.TU_TRANSFORM_SKIP) if ts else int(rng.integers(0, 4))
             c = H.random_block(rng, w, h, density=0.5, big=0.1)
+            if wide and s == 3 and not ts:
+                c[0, 0] = 40000
             ch = int(rng.integers(0, 2))
             geom.append((w, h, ch, fl)); coeffs.append(c.ravel()); blk_at.append(int(at))
             parts.append(orc.ops_to_records(ops[prev:int(at)]) if at > prev else np.zeros(0, np.uint16))
