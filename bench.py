@@ -352,6 +352,19 @@ def end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins, reps=3):
             o, n = int(desc["rec_offset"][s]), int(desc["n_records"][s])
             live[o:o + n] = True
         ok = ok and bool(np.array_equal(h_bins[live], want_bins[live]))
+        # ... and with the decoded bins packed eight to a byte (cabac_hip_decode_batch_packed): an eighth of the D2H bytes
+        if kind == "pinned":
+            kp = capi.PinnedArray(((len(records) + 7) // 8 + 1,), np.uint8)
+            keep.append(kp)
+            h_pk = kp.array
+        else:
+            h_pk = np.zeros((len(records) + 7) // 8 + 1, np.uint8)
+        t_pk = []
+        for _ in range(reps + 1):
+            t2 = time.perf_counter()
+            pk, rp = hip.decode_batch_packed(ddesc, h_rec, h_in, packed=h_pk)
+            t_pk.append(time.perf_counter() - t2)
+        ok = ok and not rp["flags"].any() and bool(np.array_equal(np.unpackbits(pk, bitorder="little")[: len(records)][live], want_bins[live]))
         coded = np.concatenate([h_out[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + (int(res["n_bits"][s]) + 7) // 8]
                                 for s in range(0, len(desc), max(len(desc) // 256, 1))])
         if ref_bytes is None:
@@ -360,8 +373,10 @@ def end_to_end_leg(hip, cfg, desc, records, bytes_total, n_bins, reps=3):
         e, d = min(t_enc[1:]), min(t_dec[1:])
         ok = ok and pay_ok
         out[kind] = {"encode_ms": round(e * 1e3, 3), "encode_payload_ms": round(min(t_pay[1:]) * 1e3, 3), "decode_ms": round(d * 1e3, 3),
+                     "decode_packed_bins_ms": round(min(t_pk[1:]) * 1e3, 3),
                      "encode_mbins_s": round(n_bins / e / 1e6, 1), "decode_mbins_s": round(n_bins / d / 1e6, 1),
-                     "mbins_s": round(2 * n_bins / (e + d) / 1e6, 1), "round_trip": bool(ok)}
+                     "mbins_s": round(2 * n_bins / (e + d) / 1e6, 1),
+                     "mbins_s_payload_and_packed": round(2 * n_bins / (min(t_pay[1:]) + min(t_pk[1:])) / 1e6, 1), "round_trip": bool(ok)}
         for k in keep:
             k.close()
     h2d_enc = 2 * n_bins + 32 * len(desc)

@@ -41,7 +41,7 @@ EXPORTS = [
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
     "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload", "cabac_hip_wait_event", "cabac_hip_record_event",
     "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual", "cabac_hip_encode_residual16_device",
-    "cabac_hip_encode_batch_residual16", "cabac_hip_gather_records_device",
+    "cabac_hip_encode_batch_residual16", "cabac_hip_decode_batch_packed", "cabac_hip_gather_records_device",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load_library():
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_decode_batch_packed.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_encode_batch_payload.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.cabac_hip_encode_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp,
                                                    vp, ctypes.c_uint64, vp, vp, vp, vp]
@@ -294,6 +295,19 @@ class CabacHip:
                                            data.ctypes.data, len(data), bins.ctypes.data, res.ctypes.data)
         self._check(rc, allow_substream=not check)
         return bins[: len(records)], res
+
+    def decode_batch_packed(self, desc, records, data, check=True, packed=None):
+        """cabac_hip_decode_batch_packed: (packed uint8[(n + 7) // 8] — bit r & 7 of byte r >> 3 = the bin of record r —, results)."""
+        desc = np.ascontiguousarray(desc, DESC_DTYPE)
+        records = np.ascontiguousarray(records, np.uint16)
+        data = np.ascontiguousarray(data, np.uint8)
+        if packed is None:
+            packed = np.zeros((len(records) + 7) // 8 + 1, np.uint8)
+        res = np.zeros(len(desc), RESULT_DTYPE)
+        rc = self.L.cabac_hip_decode_batch_packed(self.h, len(desc), desc.ctypes.data, records.ctypes.data, len(records),
+                                                  data.ctypes.data, len(data), packed.ctypes.data, res.ctypes.data)
+        self._check(rc, allow_substream=not check)
+        return packed[: (len(records) + 7) // 8], res
 
     # ---- device-pointer entry points (raw addresses, e.g. torch tensor .data_ptr()) ----------
     def encode_device(self, n_sub, d_desc, d_records, d_bytes, d_results):

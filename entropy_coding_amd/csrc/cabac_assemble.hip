@@ -146,6 +146,27 @@ hipError_t launch_gather_records(hipStream_t st, uint32_t n_seg, const uint64_t 
   return hipGetLastError();
 }
 
+// decoded bins, one byte each, packed eight to a byte: bit (r & 7) of packed[r >> 3] = bins[r] & 1.  What the host-pointer
+// decode hands back when asked to (cabac_hip_decode_batch_packed): an eighth of the bytes over PCIe.
+__global__ __launch_bounds__(256) void pack_bins_kernel(uint64_t n, const uint8_t *__restrict__ bins, uint8_t *__restrict__ packed) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256u + threadIdx.x, i = b * 8u;
+  if (i >= n) return;
+  uint32_t v = 0;
+  if (i + 8u <= n) {
+    const uint64_t w = *reinterpret_cast<const uint64_t *>(bins + i) & 0x0101010101010101ull;   // (hipMalloc'd, i a multiple of 8)
+    v = (uint32_t)((w * 0x0102040810204080ull) >> 56);
+  } else {
+    for (uint64_t k = i; k < n; k++) v |= (uint32_t)(bins[k] & 1u) << (k - i);
+  }
+  packed[b] = (uint8_t)v;
+}
+
+hipError_t launch_pack_bins(hipStream_t st, uint64_t n, const uint8_t *bins, uint8_t *packed) {
+  const uint64_t bytes = (n + 7u) / 8u;
+  if (bytes) hipLaunchKernelGGL(pack_bins_kernel, dim3((uint32_t)((bytes + 255u) / 256u)), dim3(256), 0, st, n, bins, packed);
+  return hipGetLastError();
+}
+
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,
                            uint64_t payload_capacity, uint64_t *offsets) {

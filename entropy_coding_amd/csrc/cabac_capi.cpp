@@ -792,9 +792,10 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
   return status;
 }
 
+// packed: `bins` receives (n_records_total + 7) / 8 bytes, bit (r & 7) of byte r >> 3 = the bin of record r
 static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                              uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
-                             cabac_substream_result *results) {
+                             cabac_substream_result *results, bool packed) {
   if (!c || (n_sub && (!desc || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   if (n_sub == 0) return CABAC_HIP_OK;
   int rc = check_desc_host(c, n_sub, desc, n_records_total, bytes_total);
@@ -809,7 +810,8 @@ static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
   if ((rc = ensure(c, 1, n_records_total * 2))) return rc;
   if ((rc = ensure(c, 2, bytes_total + 4))) return rc;
   if ((rc = ensure(c, 3, res_bytes))) return rc;
-  if ((rc = ensure(c, 4, n_records_total))) return rc;
+  if ((rc = ensure(c, 4, n_records_total + 8))) return rc;
+  if (packed && bins && (rc = ensure(c, 6, (n_records_total + 7) / 8 + 8))) return rc;
   if ((rc = ensure_pinned(c, 0, res_bytes))) return rc;
   auto *d_desc = static_cast<const cabac_substream_desc *>(c->d_buf[0]);
   auto *d_rec = static_cast<uint16_t *>(c->d_buf[1]);
@@ -838,7 +840,11 @@ static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
     HIP_TRY(c, hipEventRecord(c->ev_k[k], ks));
     // the decoded bins of the chunk leave while the next chunk is decoded
     HIP_TRY(c, hipStreamWaitEvent(c->s_out, c->ev_k[k], 0));
-    if (bins && (rc = d2h(c, bins + ch.rec_lo, d_bins + ch.rec_lo, ch.rec_hi - ch.rec_lo, c->s_out))) return rc;
+    if (bins && !packed && (rc = d2h(c, bins + ch.rec_lo, d_bins + ch.rec_lo, ch.rec_hi - ch.rec_lo, c->s_out))) return rc;
+  }
+  if (bins && packed) {  // all chunks decoded (s_out waits for each of them above): eight bins to a byte, one small copy
+    HIP_TRY(c, cabac::launch_pack_bins(c->s_out, n_records_total, d_bins, static_cast<uint8_t *>(c->d_buf[6])));
+    if ((rc = d2h(c, bins, c->d_buf[6], (n_records_total + 7) / 8, c->s_out))) return rc;
   }
   if ((rc = d2h_drain(c))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->s_out));
@@ -855,7 +861,13 @@ static int decode_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_subst
 int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                            uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *bins,
                            cabac_substream_result *results) {
-  return host_call_exit(c, decode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, bins, results));
+  return host_call_exit(c, decode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, bins, results, false));
+}
+
+int cabac_hip_decode_batch_packed(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                  uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *packed_bins,
+                                  cabac_substream_result *results) {
+  return host_call_exit(c, decode_batch_impl(c, n_sub, desc, records, n_records_total, bytes, bytes_total, packed_bins, results, true));
 }
 
 int cabac_hip_binarize_device(cabac_hip_ctx *c, uint32_t n_sub, const uint64_t *d_se_offset, const uint32_t *d_se,

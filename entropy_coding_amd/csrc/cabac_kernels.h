@@ -75,6 +75,7 @@ hipError_t launch_bin_count(hipStream_t st, uint32_t n_sub, const cabac_substrea
 hipError_t launch_assemble(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc,
                            const cabac_substream_result *results, const uint8_t *bytes, uint8_t *payload,
                            uint64_t payload_capacity, uint64_t *offsets);
+hipError_t launch_pack_bins(hipStream_t st, uint64_t n, const uint8_t *bins, uint8_t *packed);
 hipError_t launch_gather_records(hipStream_t st, uint32_t n_seg, const uint64_t *src_off, const uint64_t *dst_off, const uint32_t *len,
                                  const uint16_t *src, uint16_t *dst);
 hipError_t launch_split(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint64_t *offsets,

@@ -424,6 +424,12 @@ int cabac_hip_encode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_subst
 int cabac_hip_decode_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
                            const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
                            uint64_t bytes_total, uint8_t *bins, cabac_substream_result *results);
+/* The same decode with the bins packed eight to a byte: packed_bins holds (n_records_total + 7) / 8 bytes, bit (r & 7) of byte
+ * r >> 3 is the bin of record r (r counted in records[], as desc[s].rec_offset does).  An eighth of the bytes come back over PCIe
+ * (decodeBin on the host then is a bit test instead of a byte load).                                                      */
+int cabac_hip_decode_batch_packed(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc,
+                                  const uint16_t *records, uint64_t n_records_total, const uint8_t *bytes,
+                                  uint64_t bytes_total, uint8_t *packed_bins, cabac_substream_result *results);
 /* The same encode with the output as a multiplexer wants it: the coded substreams back to back in descriptor order —
  * what OutputBitstream::addSubstream (bit_stream.cpp:139-150) makes of byte-aligned substreams (code them with
  * CABAC_SUB_ALIGN_RBSP) — in payload[0 .. payload_offsets[n_sub]), substream s at payload_offsets[s] ..

@@ -168,6 +168,18 @@ int cabac_hip_decode_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substre
   return status;
 }
 
+int cabac_hip_decode_batch_packed(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
+                                  uint64_t n_records_total, const uint8_t *bytes, uint64_t bytes_total, uint8_t *packed_bins,
+                                  cabac_substream_result *results) {
+  std::vector<uint8_t> bins(n_records_total ? n_records_total : 1, 0);
+  const int rc = cabac_hip_decode_batch(c, n_sub, desc, records, n_records_total, bytes, bytes_total, packed_bins ? bins.data() : nullptr, results);
+  if (packed_bins) {
+    std::fill(packed_bins, packed_bins + (n_records_total + 7) / 8, uint8_t(0));
+    for (uint64_t r = 0; r < n_records_total; r++) packed_bins[r >> 3] |= uint8_t((bins[r] & 1u) << (r & 7));
+  }
+  return rc;
+}
+
 int cabac_hip_estimate_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint16_t *records,
                              uint64_t n_records_total, uint64_t *frac_bits, uint32_t *flags) {
   if (!c || (n_sub && (!desc || !frac_bits))) return fail(c, CABAC_HIP_ERR_INVALID, "null");

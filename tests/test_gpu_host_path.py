@@ -60,6 +60,17 @@ def _check_against_oracle(hip, desc, records, total, pinned):
     bins_o, ro = orc.decode_batch(dd, records, out_o)
     assert np.array_equal(rd["flags"], ro["flags"]) and np.array_equal(rd["n_bits"], ro["n_bits"])
     assert np.array_equal(bins_g[: len(records)], bins_o) and np.array_equal(bins_o, (records >> 15).astype(np.uint8))
+    # ... and with the bins packed eight to a byte (cabac_hip_decode_batch_packed): the same bins, bit r & 7 of byte r >> 3
+    pk = capi.PinnedArray(((len(records) + 7) // 8 + 1,), np.uint8) if pinned else None
+    packed, rp = hip.decode_batch_packed(dd, h_rec, h_out, check=False, packed=pk.array if pinned else None)
+    assert np.array_equal(rp["flags"], ro["flags"]) and np.array_equal(rp["n_bits"], ro["n_bits"])
+    unpacked = np.unpackbits(packed, bitorder="little")[: len(records)]
+    inside = np.zeros(len(records), bool)                    # (records between substreams, if any, are nobody's)
+    for s in range(len(dd)):
+        inside[int(dd["rec_offset"][s]): int(dd["rec_offset"][s]) + int(dd["n_records"][s])] = True
+    assert np.array_equal(unpacked[inside], bins_o[inside])
+    if pk is not None:
+        pk.close()
     for k in keep:
         k.close()
 
