@@ -566,6 +566,29 @@ def residual_leg(hip, n_tiles, unique=256, reps=4, host_e2e=True):
                    and bool(torch.equal(t_dec, t_co)))
     bytes_p = out_bytes + 4 * n_coef_total(c_u, copies) + (16 + 8) * n + 40 * n_tiles
     ok = ok and parsed_back
+    parse_host = None
+    if host_e2e:
+        # ... and host memory to host memory (cabac_hip_residual_parse_batch / _batch16): the bytes go up, the blocks come back —
+        # as int32 (with the caller's buffer uploaded first: what the parser does not write keeps its values) and as int16
+        h_in = t_bytes.cpu().numpy()
+        h_first = (np.arange(n_tiles + 1, dtype=np.int64) * per_tile).astype(np.uint32)
+        want_co = t_co.cpu().numpy()
+        parse_host = {}
+        for name, dt in (("int32", np.int32), ("int16", np.int16)):
+            if dt == np.int16 and not (int(want_co.min()) >= -32768 and int(want_co.max()) <= 32767):
+                continue
+            kp = capi.PinnedArray((c_u * copies,), dt)
+            t_h = []
+            for _ in range(3):
+                kp.array[:] = 0
+                t0 = time.perf_counter()
+                co_h, res_h = hip.residual_parse_batch(ddesc, h_in, h_first, all_tus, c_u * copies, int16=(dt == np.int16), coeff=kp.array)
+                t_h.append(time.perf_counter() - t0)
+            okh = not res_h["flags"].any() and bool(np.array_equal(co_h.astype(np.int32), want_co))
+            parse_host[name] = {"call_ms": round(min(t_h[1:]) * 1e3, 3), "mcoeff_s": round(c_u * copies / min(t_h[1:]) / 1e6, 1),
+                                "d2h_bytes": int(dt().itemsize * c_u * copies), "coefficients_match": bool(okh)}
+            ok = ok and okh
+            kp.close()
     n_coef = c_u * copies
     bytes1 = 4 * n_coef + (16 + 4 + 4) * n
     bytes2 = 4 * n_coef + 2 * n_bins + (16 + 8 + 4 + 4) * n
@@ -592,7 +615,7 @@ def residual_leg(hip, n_tiles, unique=256, reps=4, host_e2e=True):
                       "mbins_s": round(n_bins / (parse_ms * 1e-3) / 1e6, 1), "mcoeff_s": round(n_coef / (parse_ms * 1e-3) / 1e6, 1),
                       "algorithmic_bytes_per_launch": bytes_p, "achieved_gbps": round(bytes_p / (parse_ms * 1e-3) / 1e9, 2),
                       "frac_of_hbm_peak": round(bytes_p / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                      "coefficients_match": bool(parsed_back)},
+                      "coefficients_match": bool(parsed_back), "from_host": parse_host},
             "records_match_reference": bool(ok)}
 
 

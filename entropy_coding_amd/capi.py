@@ -41,7 +41,8 @@ EXPORTS = [
     "cabac_hip_host_alloc", "cabac_hip_host_free", "cabac_hip_host_register", "cabac_hip_host_unregister",
     "cabac_hip_host_is_pinned", "cabac_hip_encode_batch_payload", "cabac_hip_wait_event", "cabac_hip_record_event",
     "cabac_hip_encode_residual_device", "cabac_hip_encode_batch_residual", "cabac_hip_encode_residual16_device",
-    "cabac_hip_encode_batch_residual16", "cabac_hip_decode_batch_packed", "cabac_hip_gather_records_device",
+    "cabac_hip_encode_batch_residual16", "cabac_hip_decode_batch_packed", "cabac_hip_residual_parse16_device",
+    "cabac_hip_residual_parse_batch16", "cabac_hip_gather_records_device",
 ]
 
 _lib = None
@@ -100,6 +101,8 @@ def load_library():
     L.cabac_hip_residual_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_parse_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_parse_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_residual_parse_batch16.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
+    L.cabac_hip_residual_parse16_device.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     L.cabac_hip_residual_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64]
     L.cabac_hip_encode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp]
     L.cabac_hip_decode_batch.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
@@ -347,21 +350,24 @@ class CabacHip:
         self._check(self.L.cabac_hip_residual_device(self.h, n_tu, vp(d_tu), vp(d_coeff), vp(d_rec_offset),
                                                      vp(d_n_records), vp(d_info), vp(d_records)))
 
-    def residual_parse_device(self, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results, d_tu_info=0):
-        """cabac_hip_residual_parse_device: bytes -> coefficient blocks, contexts derived on the device."""
-        self._check(self.L.cabac_hip_residual_parse_device(self.h, n_sub, vp(d_desc), vp(d_bytes), vp(d_tile_first), vp(d_tu),
+    def residual_parse_device(self, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_results, d_tu_info=0, int16=False):
+        """cabac_hip_residual_parse_device (int16: cabac_hip_residual_parse16_device): bytes -> coefficient blocks, contexts
+        derived on the device."""
+        self._check((self.L.cabac_hip_residual_parse16_device if int16 else self.L.cabac_hip_residual_parse_device)(self.h, n_sub, vp(d_desc), vp(d_bytes), vp(d_tile_first), vp(d_tu),
                                                            vp(d_coeff), vp(d_tu_info) if d_tu_info else None, vp(d_results)))
 
-    def residual_parse_batch(self, desc, data, tile_first, tus, n_coeff_total, check=True, with_info=False):
-        """Host arrays in, (coeff, results[, info]) out (cabac_hip_residual_parse_batch, synchronous)."""
+    def residual_parse_batch(self, desc, data, tile_first, tus, n_coeff_total, check=True, with_info=False, int16=False, coeff=None):
+        """Host arrays in, (coeff, results[, info]) out (cabac_hip_residual_parse_batch, synchronous; int16:
+        cabac_hip_residual_parse_batch16, the blocks as int16)."""
         desc = np.ascontiguousarray(desc, DESC_DTYPE)
         data = np.ascontiguousarray(data, np.uint8)
         tile_first = np.ascontiguousarray(tile_first, np.uint32)
         tus = np.ascontiguousarray(tus, TU_DTYPE)
-        coeff = np.zeros(max(int(n_coeff_total), 1), np.int32)
+        if coeff is None:
+            coeff = np.zeros(max(int(n_coeff_total), 1), np.int16 if int16 else np.int32)
         res = np.zeros(max(len(desc), 1), RESULT_DTYPE)
         info = np.zeros(max(len(tus), 1), np.uint32)
-        rc = self.L.cabac_hip_residual_parse_batch(self.h, len(desc), desc.ctypes.data, data.ctypes.data, len(data),
+        rc = (self.L.cabac_hip_residual_parse_batch16 if int16 else self.L.cabac_hip_residual_parse_batch)(self.h, len(desc), desc.ctypes.data, data.ctypes.data, len(data),
                                                    tile_first.ctypes.data, tus.ctypes.data, coeff.ctypes.data, int(n_coeff_total),
                                                    info.ctypes.data, res.ctypes.data)
         self._check(rc, allow_substream=not check)

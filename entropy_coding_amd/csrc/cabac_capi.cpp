@@ -947,23 +947,35 @@ int cabac_hip_residual_batch(cabac_hip_ctx *c, uint32_t n_tu, const cabac_tu_des
   return status;
 }
 
-int cabac_hip_residual_parse_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc,
-                                    const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
-                                    int32_t *d_coeff, uint32_t *d_tu_info, cabac_substream_result *d_results) {
+static int residual_parse_device_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint8_t *d_bytes,
+                                      const uint32_t *d_tile_first, const cabac_tu_desc *d_tu, void *d_coeff, int coeff_bytes,
+                                      uint32_t *d_tu_info, cabac_substream_result *d_results) {
   if (!c || (n_sub && (!d_desc || !d_bytes || !d_tile_first || !d_tu || !d_coeff || !d_results)))
     return fail(c, CABAC_HIP_ERR_INVALID, "null");
   DeviceGuard g(c->device);
   Bracket br = bracket_for(c, 9);
   HIP_TRY(c, hipEventRecord(br.a, c->stream));
-  HIP_TRY(c, cabac::launch_residual_parse(c->stream, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, d_tu_info, d_results));
+  HIP_TRY(c, cabac::launch_residual_parse(c->stream, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, coeff_bytes, d_tu_info, d_results));
   HIP_TRY(c, hipEventRecord(br.b, c->stream));
   c->timed = (br.a == c->ev_start);
   return CABAC_HIP_OK;
 }
 
-int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
-                                   uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
-                                   uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {
+int cabac_hip_residual_parse_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint8_t *d_bytes,
+                                    const uint32_t *d_tile_first, const cabac_tu_desc *d_tu, int32_t *d_coeff, uint32_t *d_tu_info,
+                                    cabac_substream_result *d_results) {
+  return residual_parse_device_impl(c, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, 4, d_tu_info, d_results);
+}
+
+int cabac_hip_residual_parse16_device(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *d_desc, const uint8_t *d_bytes,
+                                      const uint32_t *d_tile_first, const cabac_tu_desc *d_tu, int16_t *d_coeff, uint32_t *d_tu_info,
+                                      cabac_substream_result *d_results) {
+  return residual_parse_device_impl(c, n_sub, d_desc, d_bytes, d_tile_first, d_tu, d_coeff, 2, d_tu_info, d_results);
+}
+
+static int residual_parse_batch_impl(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                     uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, void *coeff, int coeff_bytes,
+                                     uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {
   if (!c || (n_sub && (!desc || !bytes || !tile_first || !tus || !coeff || !results))) return fail(c, CABAC_HIP_ERR_INVALID, "null");
   if (n_sub == 0) return CABAC_HIP_OK;
   const uint32_t n_tu = tile_first[n_sub];
@@ -986,7 +998,7 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
   if ((rc = ensure(c, 0, n_sub * sizeof(cabac_substream_desc)))) return rc;
   if ((rc = ensure(c, 2, bytes_total))) return rc;
   if ((rc = ensure(c, 3, first_pad + size_t(n_tu) * sizeof(cabac_tu_desc)))) return rc;
-  if ((rc = ensure(c, 1, n_coeff_total * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, 1, (n_coeff_total + 4) * size_t(coeff_bytes)))) return rc;
   if ((rc = ensure(c, 4, n_sub * sizeof(cabac_substream_result)))) return rc;
   if ((rc = ensure(c, 6, size_t(n_tu) * sizeof(uint32_t)))) return rc;
   uint8_t *d_first = static_cast<uint8_t *>(c->d_buf[3]);
@@ -994,14 +1006,16 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
   if (bytes_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[2], bytes, bytes_total, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(d_first, tile_first, first_bytes, hipMemcpyHostToDevice, c->stream));
   if (n_tu) HIP_TRY(c, hipMemcpyAsync(d_first + first_pad, tus, size_t(n_tu) * sizeof(cabac_tu_desc), hipMemcpyHostToDevice, c->stream));
-  // what the parser does not write (outside the coded region of 64-wide blocks) keeps the caller's values
-  if (n_coeff_total) HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], coeff, n_coeff_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  rc = cabac_hip_residual_parse_device(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint8_t *)c->d_buf[2],
-                                       (const uint32_t *)d_first, (const cabac_tu_desc *)(d_first + first_pad),
-                                       (int32_t *)c->d_buf[1], (uint32_t *)c->d_buf[6], (cabac_substream_result *)c->d_buf[4]);
+  // int32: what the parser does not write (outside the coded region of 64-wide blocks) keeps the caller's values;
+  // int16: output only, zero where nothing is written
+  if (n_coeff_total && coeff_bytes == 4) HIP_TRY(c, hipMemcpyAsync(c->d_buf[1], coeff, n_coeff_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (n_coeff_total && coeff_bytes == 2) HIP_TRY(c, hipMemsetAsync(c->d_buf[1], 0, n_coeff_total * sizeof(int16_t), c->stream));
+  rc = residual_parse_device_impl(c, n_sub, (const cabac_substream_desc *)c->d_buf[0], (const uint8_t *)c->d_buf[2],
+                                  (const uint32_t *)d_first, (const cabac_tu_desc *)(d_first + first_pad), c->d_buf[1], coeff_bytes,
+                                  (uint32_t *)c->d_buf[6], (cabac_substream_result *)c->d_buf[4]);
   if (rc) return rc;
   if (tu_info && n_tu) HIP_TRY(c, hipMemcpyAsync(tu_info, c->d_buf[6], size_t(n_tu) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  if (n_coeff_total) HIP_TRY(c, hipMemcpyAsync(coeff, c->d_buf[1], n_coeff_total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (n_coeff_total) HIP_TRY(c, hipMemcpyAsync(coeff, c->d_buf[1], n_coeff_total * size_t(coeff_bytes), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(results, c->d_buf[4], n_sub * sizeof(cabac_substream_result), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   int status = CABAC_HIP_OK;
@@ -1009,6 +1023,18 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
     if (results[s].flags) status = CABAC_HIP_ERR_SUBSTREAM;
   if (status) c->last_error = "substream flag set (see results[].flags)";
   return status;
+}
+
+int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                   uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff,
+                                   uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {
+  return residual_parse_batch_impl(c, n_sub, desc, bytes, bytes_total, tile_first, tus, coeff, 4, n_coeff_total, tu_info, results);
+}
+
+int cabac_hip_residual_parse_batch16(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                     uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int16_t *coeff,
+                                     uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {
+  return residual_parse_batch_impl(c, n_sub, desc, bytes, bytes_total, tile_first, tus, coeff, 2, n_coeff_total, tu_info, results);
 }
 
 // ---- coefficients -> bytes (cabac_splice.hip) -------------------------------------------------------------------

@@ -53,8 +53,8 @@ hipError_t launch_residual(hipStream_t st, uint32_t n_tu, const cabac_tu_desc *t
 // residual parser (cabac_residual.hip): bytes -> coefficient blocks, one substream = blocks [tile_first[s], tile_first[s+1])
 // (cabac_residual_parse.hip); tu_info (may be null): per block scanPosLast | CABAC_TU_INFO_*
 hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
-                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff, uint32_t *tu_info,
-                                 cabac_substream_result *results);
+                                 const uint32_t *tile_first, const cabac_tu_desc *tus, void *coeff, int coeff_bytes /* 4 or 2 */,
+                                 uint32_t *tu_info, cabac_substream_result *results);
 
 // residual records spliced into host-recorded substreams (cabac_splice.hip); array sizes: pre n_splice + n_sub + 1,
 // sub_n / sub_cap / rec_base / byte_base n_sub, seen n_tu, err 1, totals 3 ({records, bytes, error})

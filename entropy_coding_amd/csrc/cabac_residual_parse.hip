@@ -654,11 +654,13 @@ __device__ __forceinline__ void parse_ts(D &d, uint4 *ctx, int32_t *blk, const L
 
 }  // namespace
 
-template <int W>
+// C: the type the coefficients are stored as — int32_t (the reference's TCoeff) or int16_t (streams of 15-bit dynamic range: half
+// the bytes back over PCIe for the host-pointer path; a level that does not fit sets CABAC_RES_RANGE and is stored truncated)
+template <int W, class C>
 __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, const cabac_substream_desc *__restrict__ desc,
                                                                   const uint8_t *__restrict__ bytes,
                                                                   const uint32_t *__restrict__ tile_first,
-                                                                  const cabac_tu_desc *__restrict__ tus, int32_t *__restrict__ coeff_all,
+                                                                  const cabac_tu_desc *__restrict__ tus, C *__restrict__ coeff_all,
                                                                   uint32_t *__restrict__ tu_info,
                                                                   cabac_substream_result *__restrict__ results) {
   __shared__ uint4 ctx_all[W * kCtxSlots];
@@ -763,11 +765,15 @@ __global__ __launch_bounds__(64 * W) void residual_parse_kernel(uint32_t n_sub, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int32_t *out = coeff_all + tu.coeff_offset;
+    C *out = coeff_all + tu.coeff_offset;
+    uint32_t outside = 0;  // int16_t: a level beyond the type
     for (uint32_t i = lane; i < g.we * g.he; i += 64u) {
-      out[((i >> g.lwe) << lw) + (i & (g.we - 1u))] = blk[i];
+      const int32_t v = blk[i];
+      out[((i >> g.lwe) << lw) + (i & (g.we - 1u))] = (C)v;
+      if (sizeof(C) == 2) outside |= ((uint32_t)v + 32768u) >> 16;
       blk[i] = 0;
     }
+    if (sizeof(C) == 2 && __ballot(outside != 0u) != 0ull) flags_out |= CABAC_RES_RANGE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -844,18 +850,27 @@ hipError_t debug_read_parse_prof(unsigned long long *out) {
 }
 #endif
 
-hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
-                                 const uint32_t *tile_first, const cabac_tu_desc *tus, int32_t *coeff, uint32_t *tu_info,
-                                 cabac_substream_result *results) {
-  if (n_sub == 0) return hipSuccess;
+template <class C>
+static hipError_t launch_residual_parse_as(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                           const uint32_t *tile_first, const cabac_tu_desc *tus, C *coeff, uint32_t *tu_info,
+                                           cabac_substream_result *results) {
   // four waves per workgroup, one per SIMD of the CU; small batches spread single waves over the chip
   if (n_sub >= 1024u)
-    hipLaunchKernelGGL(residual_parse_kernel<4>, dim3((n_sub + 3u) / 4u), dim3(256), 0, st, n_sub, desc, bytes, tile_first, tus,
+    hipLaunchKernelGGL((residual_parse_kernel<4, C>), dim3((n_sub + 3u) / 4u), dim3(256), 0, st, n_sub, desc, bytes, tile_first, tus,
                        coeff, tu_info, results);
   else
-    hipLaunchKernelGGL(residual_parse_kernel<1>, dim3(n_sub), dim3(64), 0, st, n_sub, desc, bytes, tile_first, tus, coeff, tu_info,
+    hipLaunchKernelGGL((residual_parse_kernel<1, C>), dim3(n_sub), dim3(64), 0, st, n_sub, desc, bytes, tile_first, tus, coeff, tu_info,
                        results);
   return hipGetLastError();
+}
+
+hipError_t launch_residual_parse(hipStream_t st, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                 const uint32_t *tile_first, const cabac_tu_desc *tus, void *coeff, int coeff_bytes, uint32_t *tu_info,
+                                 cabac_substream_result *results) {
+  if (n_sub == 0) return hipSuccess;
+  if (coeff_bytes == 2) return launch_residual_parse_as(st, n_sub, desc, bytes, tile_first, tus, static_cast<int16_t *>(coeff), tu_info, results);
+  if (coeff_bytes == 4) return launch_residual_parse_as(st, n_sub, desc, bytes, tile_first, tus, static_cast<int32_t *>(coeff), tu_info, results);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace cabac

@@ -577,12 +577,27 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
   std::vector<uint8_t> bytes(byte_total ? byte_total : 16, 0);
   for (uint32_t s = 0; s < n; s++)
     if (jobs[s].n_bytes) std::memcpy(bytes.data() + desc[s].byte_offset, jobs[s].bytes, jobs[s].n_bytes);
-  std::vector<int32_t> coeff(coeff_total ? coeff_total : 1, 0);
   std::vector<cabac_substream_result> res(n);
+  bool narrow = !tus.empty();  // every block of 15-bit dynamic range: the blocks come back as int16 (half the bytes over PCIe)
+  for (const cabac_tu_desc &t : tus) narrow = narrow && (t.max_log2_tr_range == 0 || t.max_log2_tr_range <= 15);
   if (tus.empty()) tus.push_back(cabac_tu_desc{});
   if (info_out) info_out->assign(tus.size(), 0u);
-  const int rc = cabac_hip_residual_parse_batch(handle(), n, desc.data(), bytes.data(), bytes.size(), first.data(), tus.data(),
-                                                coeff.data(), coeff_total, info_out ? info_out->data() : nullptr, res.data());
+  std::vector<int16_t> coeff16;
+  std::vector<int32_t> coeff;
+  int rc = CABAC_HIP_OK;
+  if (narrow) {
+    coeff16.assign(coeff_total ? coeff_total : 1, 0);
+    rc = cabac_hip_residual_parse_batch16(handle(), n, desc.data(), bytes.data(), bytes.size(), first.data(), tus.data(), coeff16.data(),
+                                          coeff_total, info_out ? info_out->data() : nullptr, res.data());
+    if (rc == CABAC_HIP_ERR_SUBSTREAM)
+      for (uint32_t s = 0; s < n; s++)
+        if (res[s].flags & CABAC_RES_RANGE) narrow = false;  // a level beyond what the stream declares: once more, in 32 bits
+  }
+  if (!narrow) {
+    coeff.assign(coeff_total ? coeff_total : 1, 0);
+    rc = cabac_hip_residual_parse_batch(handle(), n, desc.data(), bytes.data(), bytes.size(), first.data(), tus.data(), coeff.data(),
+                                        coeff_total, info_out ? info_out->data() : nullptr, res.data());
+  }
   if (rc == CABAC_HIP_ERR_SUBSTREAM) {
     for (uint32_t s = 0; s < n; s++) {
       if (res[s].flags & CABAC_RES_UNDERRUN) throw Exception("FIFO exceeded");
@@ -595,7 +610,8 @@ std::vector<std::vector<int32_t>> HipBatch::residualParse(const std::vector<Pars
   for (uint32_t s = 0; s < n; s++) {
     uint64_t len = 0;
     for (const ResidualBlock &b : jobs[s].blocks) len += uint64_t(b.width) * b.height;
-    out[s].assign(coeff.begin() + at, coeff.begin() + at + len);
+    if (narrow) out[s].assign(coeff16.begin() + at, coeff16.begin() + at + len);
+    else out[s].assign(coeff.begin() + at, coeff.begin() + at + len);
     at += len;
   }
   return out;

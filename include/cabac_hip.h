@@ -132,6 +132,7 @@ typedef struct cabac_substream_result {
                                       bit_stream.cpp:269: the reference throws there); the   \
                                       bins from that read on and n_bits are unspecified      */
 #define CABAC_RES_BAD_STOP 0x8u    /* decode: finish() stop/alignment pattern check failed   */
+#define CABAC_RES_RANGE 0x10u      /* residual_parse16: a coefficient does not fit int16_t (stored truncated) */
 
 typedef enum cabac_hip_status {
   CABAC_HIP_OK = 0,
@@ -467,6 +468,11 @@ int cabac_hip_estimate_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_sub
 int cabac_hip_residual_parse_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
                                     const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
                                     int32_t *d_coeff, uint32_t *d_tu_info, cabac_substream_result *d_results);
+/* The same with the blocks stored as int16_t (d_tu[t].coeff_offset counts int16_t then): for streams of 15-bit dynamic range.  A
+ * level that does not fit is stored truncated and sets CABAC_RES_RANGE in the substream's result.                          */
+int cabac_hip_residual_parse16_device(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *d_desc,
+                                      const uint8_t *d_bytes, const uint32_t *d_tile_first, const cabac_tu_desc *d_tu,
+                                      int16_t *d_coeff, uint32_t *d_tu_info, cabac_substream_result *d_results);
 
 /* Host-pointer form of cabac_hip_residual_parse_device (synchronous).  bytes_total / n_coeff_total bound the two
  * buffers; coeff receives the blocks at tus[t].coeff_offset, tu_info (may be NULL) one word per block.  Returns
@@ -475,6 +481,13 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *ctx, uint32_t n_sub, const cab
                                    uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus,
                                    int32_t *coeff, uint64_t n_coeff_total, uint32_t *tu_info,
                                    cabac_substream_result *results);
+/* ... with the blocks as int16_t (see cabac_hip_residual_parse16_device): half the bytes back over PCIe, and nothing up — coeff is
+ * output only here: what the parser does not write (outside the coded top-left 32 x 32 of 64-wide / tall blocks, blocks behind
+ * the one at which a substream stops) is zero.                                                                             */
+int cabac_hip_residual_parse_batch16(cabac_hip_ctx *ctx, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                     uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus,
+                                     int16_t *coeff, uint64_t n_coeff_total, uint32_t *tu_info,
+                                     cabac_substream_result *results);
 
 /* Host-pointer form of cabac_hip_residual_device (synchronous, both passes).  `offsets` receives n_tu + 1 record
  * offsets (block t's records are records[offsets[t] .. offsets[t+1])); n_records/info as on the device, info may

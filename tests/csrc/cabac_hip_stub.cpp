@@ -360,4 +360,14 @@ int cabac_hip_residual_parse_batch(cabac_hip_ctx *c, uint32_t n_sub, const cabac
   return status;
 }
 
+int cabac_hip_residual_parse_batch16(cabac_hip_ctx *c, uint32_t n_sub, const cabac_substream_desc *desc, const uint8_t *bytes,
+                                     uint64_t bytes_total, const uint32_t *tile_first, const cabac_tu_desc *tus, int16_t *coeff,
+                                     uint64_t n_coeff_total, uint32_t *tu_info, cabac_substream_result *results) {
+  std::vector<int32_t> wide(n_coeff_total ? n_coeff_total : 1, 0);
+  const int rc = cabac_hip_residual_parse_batch(c, n_sub, desc, bytes, bytes_total, tile_first, tus, wide.data(), n_coeff_total, tu_info, results);
+  if (coeff)
+    for (uint64_t i = 0; i < n_coeff_total; i++) coeff[i] = int16_t(wide[i]);
+  return rc;
+}
+
 }  // extern "C"

@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(w, h) for w in (1, 2, 4, 8, 16, 32, 64) for h in (1, 2, 4, 8, 16, 32, 64)]
 
 
-@pytest.fixture(scope="module")
-def hip():
+@pytest.fixture(scope="module", params=["int32", "int16"])
+def hip(request):
+    """Every test of this file with the blocks stored as int32 (cabac_hip_residual_parse_device) and as int16
+    (cabac_hip_residual_parse16_device: the same levels, half the bytes)."""
     c = H.gpu_ctx()
+    c.parse_int16 = request.param == "int16"
     yield c
     c.close()
 
@@ -62,15 +65,17 @@ def parse(hip, subs, qps, capacities=None, finish=True, mutate=None):
     t_buf = torch.from_numpy(buf).cuda()
     t_first = torch.from_numpy(tile_first.view(np.int32).copy()).cuda()
     t_tu = torch.from_numpy(tus.view(np.uint8).reshape(-1).copy()).cuda()
-    t_co = torch.full((max(off, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    narrow = getattr(hip, "parse_int16", False)
+    t_co = torch.full((max(off, 1),), 0x5A5A, dtype=torch.int16, device="cuda") if narrow else torch.full((max(off, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
     t_res = torch.full((2 * n_sub,), -1, dtype=torch.int32, device="cuda")
     t_info = torch.full((max(len(metas), 1),), -1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     hip.residual_parse_device(n_sub, t_desc.data_ptr(), t_buf.data_ptr(), t_first.data_ptr(), t_tu.data_ptr(), t_co.data_ptr(), t_res.data_ptr(),
-                              d_tu_info=t_info.data_ptr())
+                              d_tu_info=t_info.data_ptr(), int16=narrow)
     hip.synchronize()
     parse.last_info = t_info.cpu().numpy().view(np.uint32)
     co = t_co.cpu().numpy()
+    co = co.astype(np.int32)
     res = t_res.cpu().numpy().view(H.RESULT_DTYPE)
     out, o = [], 0
     for s in subs:
@@ -304,8 +309,9 @@ def test_host_pointer_parse_batch(hip):
     buf = np.zeros(int(slots.sum()), np.uint8)
     for s in range(len(subs)):
         buf[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + len(subs[s][2])] = subs[s][2]
-    co, res = hip.residual_parse_batch(desc, buf, first, tus, off)
-    assert not res["flags"].any()
+    narrow = getattr(hip, "parse_int16", False)
+    co, res = hip.residual_parse_batch(desc, buf, first, tus, off, int16=narrow)
+    assert not res["flags"].any() and co.dtype == (np.int16 if narrow else np.int32)
     o = 0
     for s in subs:
         for c in s[1]:
@@ -316,8 +322,8 @@ def test_host_pointer_parse_batch(hip):
     bad = desc.copy()
     bad["byte_capacity"][3] = 2
     with pytest.raises(capi.CabacHipError):
-        hip.residual_parse_batch(bad, buf, first, tus, off)
-    co2, res2 = hip.residual_parse_batch(bad, buf, first, tus, off, check=False)
+        hip.residual_parse_batch(bad, buf, first, tus, off, int16=narrow)
+    co2, res2 = hip.residual_parse_batch(bad, buf, first, tus, off, check=False, int16=narrow)
     assert int(res2["flags"][3]) & H.RES_UNDERRUN and not res2["flags"][[0, 1, 2, 4]].any()
 
 
