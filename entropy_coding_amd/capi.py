@@ -13,7 +13,7 @@ REC_BIN = 0x8000
 REC_ALIGN, REC_EP, REC_TRM = 0x1FD, 0x1FE, 0x1FF
 SUB_FINISH, SUB_ALIGN_RBSP = 0x100, 0x200
 CABAC_INIT_B, CABAC_INIT_P, CABAC_INIT_I = 0, 1, 2
-RES_OVERFLOW, RES_BAD_RECORD, RES_UNDERRUN, RES_BAD_STOP = 1, 2, 4, 8
+RES_OVERFLOW, RES_BAD_RECORD, RES_UNDERRUN, RES_BAD_STOP, RES_RANGE = 1, 2, 4, 8, 16
 
 DESC_DTYPE = np.dtype([("rec_offset", "<u8"), ("byte_offset", "<u8"), ("n_records", "<u4"),
                        ("byte_capacity", "<u4"), ("qp", "<i4"), ("init_id", "<u4")])

@@ -17,7 +17,7 @@ NUM_CTX = 379
 REC_BIN = 0x8000
 REC_ALIGN, REC_EP, REC_TRM = 0x1FD, 0x1FE, 0x1FF
 SUB_FINISH, SUB_ALIGN_RBSP = 0x100, 0x200
-RES_OVERFLOW, RES_BAD_RECORD, RES_UNDERRUN, RES_BAD_STOP = 1, 2, 4, 8   # cabac_substream_result.flags
+RES_OVERFLOW, RES_BAD_RECORD, RES_UNDERRUN, RES_BAD_STOP, RES_RANGE = 1, 2, 4, 8, 16   # cabac_substream_result.flags
 
 OP_BIN, OP_EP, OP_BINS_EP, OP_REM_ABS, OP_TRM, OP_ALIGN = 0, 1, 2, 3, 4, 5
 OP_UNARY_MAX, OP_UNARY_EP, OP_EXP_GOLOMB, OP_TRUNC_BIN = 6, 7, 8, 9

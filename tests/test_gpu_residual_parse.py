@@ -360,3 +360,39 @@ def test_sbt_zero_out_blocks_parse_back(hip):
         for k, c in enumerate(blocks):
             we, he = min(metas[k][0], 32), min(metas[k][1], 32)
             assert np.array_equal(got[s][k][:he, :we], c[:he, :we]) and np.array_equal(got[s][k][:he, :we], want[k][:he, :we]), (s, k)
+
+
+def test_int16_output_reports_a_level_that_does_not_fit():
+    """cabac_hip_residual_parse_batch16 on a stream of extended dynamic range (max_log2_tr_range 20) whose block holds a level
+    beyond int16: CABAC_RES_RANGE in that substream's result (the level is stored truncated), the other substream is not
+    touched by it; the 32-bit form gives the block back exactly.  (HipBatch::residualParse falls back on that flag.)"""
+    orc = H.load_oracle()
+    c_big = np.zeros((8, 8), np.int32)
+    c_big[0, 0], c_big[1, 2], c_big[3, 3] = 100000, -7, 2
+    c_ok = np.zeros((8, 8), np.int32)
+    c_ok[0, 0], c_ok[2, 1] = -31000, 5
+    datas = []
+    for c in (c_big, c_ok):
+        rec = np.concatenate([orc.residual_records(c, 0, 0, max_log2_range=20)[0], np.array([0x81FF], np.uint16)])
+        datas.append(orc.encode_records(rec, 30, 2, 3)[0])
+    tus = np.zeros(2, H.TU_DTYPE)
+    tus["log2_width"], tus["log2_height"], tus["max_log2_tr_range"] = 3, 3, 20
+    tus["coeff_offset"] = [0, 64]
+    desc = np.zeros(2, H.DESC_DTYPE)
+    desc["byte_offset"] = [0, (len(datas[0]) + 15) // 16 * 16 + 16]
+    desc["byte_capacity"] = [len(d) for d in datas]
+    desc["qp"], desc["init_id"] = 30, 2 | H.SUB_FINISH
+    buf = np.zeros(int(desc["byte_offset"][1]) + len(datas[1]) + 32, np.uint8)
+    for s in range(2):
+        buf[int(desc["byte_offset"][s]): int(desc["byte_offset"][s]) + len(datas[s])] = datas[s]
+    first = np.array([0, 1, 2], np.uint32)
+    hip = capi.CabacHip(0)
+    co, res = hip.residual_parse_batch(desc, buf, first, tus, 128)
+    assert not res["flags"].any() and np.array_equal(co[:64].reshape(8, 8), c_big) and np.array_equal(co[64:].reshape(8, 8), c_ok)
+    with pytest.raises(capi.CabacHipError):
+        hip.residual_parse_batch(desc, buf, first, tus, 128, int16=True)
+    co16, res16 = hip.residual_parse_batch(desc, buf, first, tus, 128, int16=True, check=False)
+    assert int(res16["flags"][0]) == capi.RES_RANGE and int(res16["flags"][1]) == 0
+    assert np.array_equal(co16[64:].reshape(8, 8), c_ok) and np.array_equal(res16["n_bits"], res["n_bits"])
+    assert np.array_equal(co16[:64].reshape(8, 8), c_big.astype(np.int16))
+    hip.close()
