@@ -157,6 +157,26 @@ def residual(ref):
         meta.append((int(np.log2(w)), int(np.log2(h)), chroma, flags))
         coeffs.append(c.ravel())
         recs.append(r)
+    # SBT / MTS zero-out (CABAC_TU_SBT_ZERO_OUT; cabac_writer.cpp:2660-2667, :2507-2516): 32-wide / tall luma blocks coded as their
+    # left / upper 16, among blocks the flag leaves alone (chroma, smaller, 64-wide); a generator of its own, appended, so that
+    # the blocks above are what they were before the flag existed
+    rng = np.random.default_rng(0x5B7601D)
+    for i, (w, h) in enumerate([(32, 32), (32, 8), (8, 32), (32, 16), (16, 32), (32, 4), (4, 32), (32, 2), (2, 32), (32, 1), (16, 16), (8, 8), (4, 4),
+                                (64, 64)] * 2):
+        chroma = 1 if i % 9 == 8 else 0
+        c = H.random_block(rng, w, h, density=[0.08, 0.5, 1.0][i % 3], big=[0.0, 0.2, 0.5][(i // 3) % 3])
+        if not chroma and max(w, h) <= 32:
+            if w == 32:
+                c[:, 16:] = 0
+            if h == 32:
+                c[16:, :] = 0
+            if not c.any():
+                c[0, min(w, 16) - 1] = -2
+        flags = int(rng.integers(0, 4)) | H.TU_SBT_ZERO_OUT
+        r, _ = ref.residual_records(c, chroma, flags)
+        meta.append((int(np.log2(w)), int(np.log2(h)), chroma, flags))
+        coeffs.append(c.ravel())
+        recs.append(r)
     out = {"n_blocks": np.array([len(meta)], np.int32), "meta": np.array(meta, np.int32),
            "coeff": np.concatenate(coeffs).astype(np.int32),
            "coeff_off": np.concatenate([[0], np.cumsum([len(c) for c in coeffs])]).astype(np.int64),
@@ -254,6 +274,36 @@ def residual_parse(ref):
         out["s%d_coeff" % s] = np.concatenate([d.ravel() for d in dec]).astype(np.int32)
         out["s%d_refinfo" % s] = np.asarray(rinfo, np.int32)
     n_sub += n_ts
+    # substreams of SBT / MTS zero-out blocks (cabac_reader.cpp:2880-2891, :2718-2727) mixed with blocks the flag leaves alone
+    rng = np.random.default_rng(0x5B7602D)
+    n_zo = 8
+    for s in range(n_sub, n_sub + n_zo):
+        qp = int(rng.integers(0, 64))
+        metas, recs = [], []
+        for k in range(int(rng.integers(3, 10))):
+            w, h = [(32, 32), (32, 8), (8, 32), (32, 16), (16, 32), (32, 4), (4, 32), (16, 16), (8, 8), (64, 32)][int(rng.integers(0, 10))]
+            ch = 1 if rng.random() < 0.15 else 0
+            c = H.random_block(rng, w, h, density=float(rng.choice([0.1, 0.5, 1.0])), big=float(rng.choice([0.0, 0.2])))
+            if not ch and max(w, h) <= 32:
+                if w == 32:
+                    c[:, 16:] = 0
+                if h == 32:
+                    c[16:, :] = 0
+                if not c.any():
+                    c[0, 0] = 3
+            fl = (H.TU_DEP_QUANT if s & 1 else 0) | H.TU_SBT_ZERO_OUT
+            metas.append((w, h, ch, fl))
+            recs.append(ref.residual_records(c, ch, fl)[0])
+        rec = np.concatenate(recs + [np.array([0x81FF], np.uint16)])
+        data, _ = ref.encode_records(rec, qp, 2, 3)
+        rc, dec, nbits, rinfo = ref.residual_decode(data, qp, metas, with_info=True)
+        assert rc == 0
+        out["s%d_meta" % s] = np.array(metas, np.int32)
+        out["s%d_qp" % s] = np.array([qp, nbits], np.int64)
+        out["s%d_bytes" % s] = data
+        out["s%d_coeff" % s] = np.concatenate([d.ravel() for d in dec]).astype(np.int32)
+        out["s%d_refinfo" % s] = np.asarray(rinfo, np.int32)
+    n_sub += n_zo
     out["n_sub"] = np.array([n_sub], np.int32)
     path = os.path.join(GOLD, "residual_parse.npz")
     np.savez_compressed(path, **out)
