@@ -596,24 +596,24 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
 
     if (kWrite && act) {
       if (ctx_mode) {
-        uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + (diag < 2u ? 4u : 0u);
-        if (chroma == 0u) ofs += diag < 5u ? 4u : 0u;
-        const uint32_t set = chroma + 2u * (my_state > 1u ? my_state - 1u : 0u);  // SigFlag[chType + 2 * max(0, state - 1)]
-        uint32_t aofs = 0;
-        if (pos != last) {  // ctxOffsetAbs, context_modelling.hpp:131-143
-          aofs = (uint32_t)min(sum_clip - n_tmpl, 4) + 1u;
-          if (diag == 0u) aofs += chroma ? 5u : 15u;
-          else if (chroma == 0u) aofs += diag < 3u ? 10u : diag < 10u ? 5u : 0u;
-        }
+        // (written as arithmetic on compare results: as nested ?: / if chains hipcc builds an exec-mask region per level)
+        const uint32_t luma = chroma ^ 1u;
+        const uint32_t ofs = min((uint32_t)(sum_clip + 1) >> 1, 3u) + 4u * ((uint32_t)(diag < 2u) + (luma & (uint32_t)(diag < 5u)));
+        const uint32_t set = chroma + 2u * (my_state - (my_state > 1u ? 1u : my_state));  // SigFlag[chType + 2 * max(0, state - 1)]
+        const uint32_t sig_base = (uint32_t)(0x8E827A6E665Aull >> (8u * set)) & 0xffu;    // 90, 102, 110, 122, 130, 142
+        // ctxOffsetAbs, context_modelling.hpp:131-143: 1 + min(sumClip - numPos, 4) + 5 * (luma: (d < 10) + (d < 3) + (d < 1); chroma: (d < 1))
+        const uint32_t steps = (uint32_t)(diag == 0u) + luma * ((uint32_t)(diag < 3u) + (uint32_t)(diag < 10u));
+        const uint32_t aofs = (pos != last ? 1u : 0u) * ((uint32_t)min(sum_clip - n_tmpl, 4) + 1u + 5u * steps);
+        const uint32_t gt1_base = 214u + 21u * chroma, par_base = 150u + 21u * chroma, gt2_base = 182u + 21u * chroma;  // GtxFlag(2 + ch), ParFlag(ch), GtxFlag(ch)
         uint16_t *o1 = out + off + spent_before;  // every position above a context-coded one is context coded
 #ifndef CABAC_EXP_NO_CTX
-        if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_SIG_FLAG(set) + ofs));
+        if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (sig_base + ofs));
         if (nzero) {
-          *o1++ = (uint16_t)((a > 1u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(2u + chroma) + aofs));
+          *o1++ = (uint16_t)((a > 1u ? CABAC_REC_BIN : 0u) | (gt1_base + aofs));
           if (a > 1u) {
             const uint32_t rem = a - 2u;
-            *o1++ = (uint16_t)(((rem & 1u) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_PAR_FLAG(chroma) + aofs));
-            *o1 = (uint16_t)(((rem >> 1) ? CABAC_REC_BIN : 0u) | (CABAC_CTX_GTX_FLAG(chroma) + aofs));
+            *o1++ = (uint16_t)(((rem & 1u) ? CABAC_REC_BIN : 0u) | (par_base + aofs));
+            *o1 = (uint16_t)(((rem >> 1) ? CABAC_REC_BIN : 0u) | (gt2_base + aofs));
           }
         }
 #endif
