@@ -605,7 +605,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
         const uint32_t steps = (uint32_t)(diag == 0u) + luma * ((uint32_t)(diag < 3u) + (uint32_t)(diag < 10u));
         const uint32_t aofs = (pos != last ? 1u : 0u) * ((uint32_t)min(sum_clip - n_tmpl, 4) + 1u + 5u * steps);
         const uint32_t gt1_base = 214u + 21u * chroma, par_base = 150u + 21u * chroma, gt2_base = 182u + 21u * chroma;  // GtxFlag(2 + ch), ParFlag(ch), GtxFlag(ch)
-        uint16_t *o1 = out + off + spent_before;  // every position above a context-coded one is context coded
+        uint16_t *o1 = out + (off + spent_before);  // every position above a context-coded one is context coded
 #ifndef CABAC_EXP_NO_CTX
         if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (sig_base + ofs));
         if (nzero) {
@@ -618,7 +618,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
         }
 #endif
       }
-      uint16_t *o2 = out + off + n_ctx_bins + before23;
+      uint16_t *o2 = out + (off + n_ctx_bins + before23);  // (one 64-bit add: the sum in 32 bits first)
 #ifndef CABAC_EXP_NO_EP
       for (uint32_t j = 0; j < ep.len1; j++) o2[j] = (uint16_t)((((ep.code1 >> (ep.len1 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
       o2 += ep.len1;
@@ -716,7 +716,7 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
       const uint32_t total3 = (uint32_t)__shfl((int)(before3 + n3), (int)(lane | 15u));
       if (kWrite && act) {
         if (pass1) {
-          uint16_t *o1 = out + off + spent1;
+          uint16_t *o1 = out + (off + spent1);
           if (sig_coded) *o1++ = (uint16_t)((nzero ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_SIG_FLAG + n_nb));
           if (nzero) {
             const int sl = (vl > 0) - (vl < 0), sa = (va > 0) - (va < 0);  // signCtxIdAbsTS, context_modelling.hpp:293-317
@@ -728,11 +728,11 @@ __device__ __forceinline__ void residual_rows(uint32_t wg_index, int32_t *stage,
           }
         }
         if (pass2) {
-          uint16_t *o2 = out + off + n1 + spent2;
+          uint16_t *o2 = out + (off + n1 + spent2);
           for (uint32_t k = 1; k <= cost2; k++)  // greater-than-(2k+1) flags, contexts TsGtxFlag(1..4)
             o2[k - 1u] = (uint16_t)((mod >= 2u * k + 2u ? CABAC_REC_BIN : 0u) | (CABAC_CTX_TS_GTX_FLAG + k));
         }
-        uint16_t *o3 = out + off + n1 + n2 + before3;
+        uint16_t *o3 = out + (off + n1 + n2 + before3);
         for (uint32_t j = 0; j < ep.len1; j++) o3[j] = (uint16_t)((((ep.code1 >> (ep.len1 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
         o3 += ep.len1;
         for (uint32_t j = 0; j < ep.len2; j++) o3[j] = (uint16_t)((((ep.code2 >> (ep.len2 - 1u - j)) & 1u) ? CABAC_REC_BIN : 0u) | CABAC_REC_EP);
