@@ -344,13 +344,23 @@ void HipBatch::flush() {
   if (m_pending.empty()) return;
   std::vector<Pending> done;
   done.swap(m_pending);
-  if (m_peers.empty()) return flushLocal(done);
-  // several devices: deal the substreams out, longest first, and code every share at the same time
   std::vector<uint64_t> weight(done.size());
   for (size_t k = 0; k < done.size(); k++) {
     weight[k] = done[k].records.size();
     for (const cabac_tu_desc &t : done[k].blocks) weight[k] += uint64_t(1) << (t.log2_width + t.log2_height);
   }
+  if (m_peers.empty()) {
+    // one device: the substreams longest first — consecutive substreams share a wave / a workgroup, which runs as long as its
+    // longest (every substream's bytes go to its own bitstream, so the order is nobody else's business)
+    std::vector<uint32_t> order(done.size());
+    for (uint32_t k = 0; k < order.size(); k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    std::vector<Pending> sorted;
+    sorted.reserve(done.size());
+    for (uint32_t k : order) sorted.push_back(std::move(done[k]));
+    return flushLocal(sorted);
+  }
+  // several devices: deal the substreams out, longest first, and code every share at the same time
   const std::vector<std::vector<uint32_t>> share = lptAssign(weight, deviceCount());
   std::vector<std::vector<Pending>> part(deviceCount());
   size_t moved_blocks = 0;
