@@ -62,6 +62,7 @@ def parser_round(hip, rng, n_sub):
         fl = int(rng.choice([0, H.TU_DEP_QUANT, H.TU_SIGN_HIDING, H.TU_SIGN_HIDING | H.TU_DEP_QUANT]))
         subs = P.build(rng, n_sub, lambda s: fl, qps)
         exact = not (fl & H.TU_SIGN_HIDING)   # random blocks are not arranged for sign hiding: the oracle's parse is the truth
+    hip.parse_int16 = bool(rng.integers(0, 2))   # the blocks stored as int16 (cabac_hip_residual_parse16_device) or as int32
     got, res = P.parse(hip, subs, qps)
     info = P.parse.last_info
     assert not res["flags"].any()
